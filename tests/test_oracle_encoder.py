@@ -1,0 +1,86 @@
+"""Pins oracle/encoder.py to the reference's encoder arithmetic (transformers WhisperEncoder) through the
+committed golden vectors.  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from mlx8_ws_audio_transformer_amd import weights as wts
+from oracle import encoder, logmel
+from tests.util import golden, piano_clips_f32
+
+G = golden("encoder.npz")
+
+
+def _mel(cfg, batch):
+    return logmel.whisper_logmel(piano_clips_f32(batch), n_samples=2 * cfg.max_source_positions * 160)
+
+
+@pytest.mark.parametrize("name,trimmed,batch", [("mini", False, 1), ("mini", True, 2), ("tiny", True, 2),
+                                                ("tiny", False, 2), ("small", True, 2)])
+def test_encoder_matches_reference(name, trimmed, batch):
+    cfg = wts.config(name, trimmed)
+    W = wts.init_encoder_weights(cfg, seed=0, profile="test")
+    key = cfg.name
+    assert bytes.fromhex(wts.weights_digest(W)) == G[f"{key}/weights_sha256"].tobytes()
+    mel = _mel(cfg, batch)
+    assert abs(mel.astype(np.float64).sum() - float(G[f"{key}/mel_sum"])) < 0.5  # inputs agree (<=1e-5 per bin)
+    out, bounds = encoder.encoder_forward(W, mel, cfg.heads, return_boundaries=True)
+    out = out.numpy()
+    tol = 2e-4  # fp32 op-order noise amplified by the mel input difference (<= 1e-5 per bin)
+    np.testing.assert_allclose(out[:, :4], G[f"{key}/last_head"], rtol=0, atol=tol)
+    np.testing.assert_allclose(out[:, -4:], G[f"{key}/last_tail"], rtol=0, atol=tol)
+    # transformers reports hidden_states = (embeddings, layer outputs...) with the LAST entry replaced by the
+    # final-LayerNorm output, so the last boundary is compared against `out`
+    bounds = bounds[:-1] + [torch.from_numpy(out)]
+    stats = np.array([[b.mean(), b.std(), b.abs().max()] for b in bounds], dtype=np.float64)
+    np.testing.assert_allclose(stats, G[f"{key}/boundary_stats"], rtol=2e-4, atol=2e-4)
+    heads = np.stack([b[:, :2].numpy() for b in bounds])
+    np.testing.assert_allclose(heads, G[f"{key}/boundary_head"], rtol=0, atol=tol)
+    if f"{key}/last_full" in G:
+        np.testing.assert_allclose(out, G[f"{key}/last_full"], rtol=0, atol=tol)
+
+
+def test_wrong_mel_length_raises_like_reference():
+    cfg = wts.config("mini")
+    W = wts.init_encoder_weights(cfg)
+    with pytest.raises(ValueError, match="length 3000"):
+        encoder.encoder_forward(W, np.zeros((1, 80, 400), np.float32), cfg.heads)
+
+
+def test_sinusoid_table_rows():
+    tab = wts.sinusoids(1500, 768)
+    np.testing.assert_allclose(tab[[0, 1, 199, 1499]], G["sinusoid_rows_768"], rtol=0, atol=1e-6)
+    np.testing.assert_array_equal(wts.sinusoids(200, 768), tab[:200])  # trimmed table = first rows
+
+
+def test_lora_zero_b_is_identity_and_nonzero_b_changes_output():
+    cfg = wts.config("mini", trimmed=True)
+    W = wts.init_encoder_weights(cfg, profile="test")
+    spec = wts.LoraSpec(r=8, alpha=16.0)
+    mel = _mel(cfg, 1)
+    base = encoder.encoder_forward(W, mel, cfg.heads).numpy()
+    W0 = dict(W, **wts.init_lora_weights(cfg, spec, zero_b=True))
+    np.testing.assert_array_equal(encoder.encoder_forward(W0, mel, cfg.heads, lora_scale=spec.scale).numpy(), base)
+    W1 = dict(W, **wts.init_lora_weights(cfg, spec, zero_b=False))
+    out = encoder.encoder_forward(W1, mel, cfg.heads, lora_scale=spec.scale).numpy()
+    assert np.abs(out - base).max() > 1e-3
+    # merged-weight identity: W + scale * B A gives the same function
+    Wm = dict(W)
+    for k in list(W1):
+        if k.endswith(".lora_A"):
+            mod = k[: -len(".lora_A")]
+            Wm[mod + ".weight"] = (W[mod + ".weight"].astype(np.float64)
+                                   + spec.scale * W1[mod + ".lora_B"].astype(np.float64) @ W1[k].astype(np.float64)).astype(np.float32)
+    merged = encoder.encoder_forward(Wm, mel, cfg.heads).numpy()
+    np.testing.assert_allclose(out, merged, rtol=0, atol=2e-5)
+
+
+def test_numerics_model_bounds():
+    """The tolerance choice of DESIGN.md: single-pass bf16 operands miss 1e-3, split-bf16 (3 products) meets it."""
+    cfg = wts.config("tiny", trimmed=True)
+    W = wts.init_encoder_weights(cfg, profile="hf")
+    mel = _mel(cfg, 1)
+    ref = encoder.encoder_forward(W, mel, cfg.heads, dtype=torch.float64).numpy()
+    e1 = encoder.error_norms(encoder.encoder_forward_emulated(W, mel, cfg.heads, 1).numpy(), ref)
+    e3 = encoder.error_norms(encoder.encoder_forward_emulated(W, mel, cfg.heads, 3).numpy(), ref)
+    assert e1["max_abs"] > 1e-3 and e3["max_abs"] < 1e-4

@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the reference's own arithmetic (build container only).
+
+What is run here, and why it pins the oracle:
+
+* `transformers` (5.15.0 in this image; the reference pins 4.35.2 / 4.53.1) -- the third-party package
+  in which every FLOP of the reference's hot path lives.  `WhisperFeatureExtractor()` (defaults are
+  Whisper's) and `WhisperEncoder(WhisperConfig(...))` are built from config, no network, and fed our own
+  deterministic weights via `load_state_dict`.
+* `/root/reference/AB/exampleDataCollator.py` -- the reference's collator, executed with `runpy` with a
+  stub `processor` / `model` injected (the file expects those names to exist; it has no imports of them).
+
+The outputs are data only (inputs are regenerated from seeds by the tests).  Nothing under
+/root/reference or site-packages is copied into the repository.  This script does not run on the GPU
+box; tests read the committed .npz files.
+"""
+from __future__ import annotations
+
+import os
+import runpy
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+import mlx8_ws_audio_transformer_amd as awt  # noqa: E402
+from mlx8_ws_audio_transformer_amd import synth, weights as wts  # noqa: E402
+
+
+def logmel_inputs():
+    """The five Whisper log-mel inputs of fixture F2 (regenerated identically by tests/util.py)."""
+    noise = (0.1 * wts.unit_variates("f2_noise", 64000, 0)).astype(np.float32)
+    tone = synth.tone_noise_clip(0)
+    zeros = np.zeros(64000, dtype=np.float32)
+    short = tone[:16000].copy()
+    piano = synth.pcm_i16_to_f32(synth.synth_clips_i16(1, seed=1234, first=3)[0])
+    return {"noise": noise, "tone": tone, "zeros": zeros, "short": short, "piano": piano}
+
+
+def gen_logmel():
+    from transformers import WhisperFeatureExtractor
+    from transformers.audio_utils import mel_filter_bank
+
+    fe = WhisperFeatureExtractor()
+    out = {"mel_filters_201x80": fe.mel_filters.astype(np.float64)}
+    for name, clip in logmel_inputs().items():
+        # the path __call__ takes when torch is importable (HF:feature_extraction_whisper.py:321-323)
+        t = fe(clip, sampling_rate=16000, return_tensors="np")["input_features"][0]
+        # the NumPy/float64 path -- the only one transformers 4.35.2 had
+        padded = np.zeros((1, 480000), dtype=np.float32)
+        padded[0, : clip.size] = clip
+        n = fe._np_extract_fbank_features(padded, "cpu")[0]
+        assert t.shape == (80, 3000) and n.shape == (80, 3000)
+        out[f"{name}_np_live"] = n[:, :404].astype(np.float32)      # 402 live frames (4 s) + 2 padding frames
+        out[f"{name}_torch_live"] = t[:, :404].astype(np.float32)
+        out[f"{name}_np_tail"] = n[:, -4:].astype(np.float32)
+        out[f"{name}_np_padconst"] = np.float32(n[0, 1500])
+        assert np.all(n[:, 404:] == n[0, 1500]) or name == "zeros", name
+    # batched call: per-clip max must not leak across clips (HF:feature_extraction_whisper.py:160-162)
+    both = fe([logmel_inputs()["tone"], logmel_inputs()["short"] * 0.01], sampling_rate=16000, return_tensors="np")
+    out["batch2_torch_live"] = both["input_features"][:, :, :404].astype(np.float32)
+    # trimmed mode (T=400): the same extractor told to pad to 64000 samples instead of 480000
+    trimmed = fe(logmel_inputs()["tone"], sampling_rate=16000, return_tensors="np", max_length=64000)
+    out["tone_torch_trimmed"] = trimmed["input_features"][0].astype(np.float32)
+    np.savez_compressed(os.path.join(GOLD, "logmel_whisper.npz"), **out)
+
+    # UrbanSound front-end (fixture F3): torch.stft fp32 + the HTK / un-normalised triangular bank
+    us = {}
+    tone = logmel_inputs()["tone"]
+    for n_mels, hop in [(80, 512), (128, 512), (128, 128), (64, 512)]:
+        fb = mel_filter_bank(513, n_mels, 0.0, 8000.0, 16000, None, "htk")
+        stft = torch.stft(torch.from_numpy(tone), 1024, hop, window=torch.hann_window(1024), center=True,
+                          pad_mode="reflect", return_complex=True)
+        mel = torch.from_numpy(fb).float().T @ (stft.abs() ** 2)
+        us[f"mels{n_mels}_hop{hop}"] = torch.log(mel + 1e-6).numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(GOLD, "logmel_urbansound.npz"), **us)
+    print("logmel fixtures written")
+
+
+def hf_encoder(cfg: wts.EncoderConfig, weights):
+    from transformers import WhisperConfig
+    from transformers.models.whisper.modeling_whisper import WhisperEncoder
+
+    hc = WhisperConfig(d_model=cfg.d_model, encoder_layers=cfg.layers, encoder_attention_heads=cfg.heads,
+                       encoder_ffn_dim=cfg.ffn, num_mel_bins=cfg.n_mels, max_source_positions=cfg.max_source_positions,
+                       decoder_layers=1, decoder_attention_heads=cfg.heads, decoder_ffn_dim=cfg.ffn)
+    hc._attn_implementation = "eager"
+    enc = WhisperEncoder(hc).eval()
+    missing, unexpected = enc.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()}, strict=True)
+    assert not missing and not unexpected
+    return enc
+
+
+def encoder_mel(cfg: wts.EncoderConfig, batch: int):
+    """Input features for the encoder fixtures: HF extractor on seeded piano clips."""
+    from transformers import WhisperFeatureExtractor
+
+    fe = WhisperFeatureExtractor()
+    clips = [synth.pcm_i16_to_f32(c) for c in synth.synth_clips_i16(batch, seed=1234, first=0)]
+    n = 2 * cfg.max_source_positions * 160
+    return fe(clips, sampling_rate=16000, return_tensors="np", max_length=n)["input_features"].astype(np.float32)
+
+
+def gen_encoder():
+    out = {}
+    for name, trimmed, batch, full in [("mini", False, 1, True), ("mini", True, 2, True),
+                                       ("tiny", False, 2, False), ("tiny", True, 2, False),
+                                       ("small", False, 2, False), ("small", True, 2, False)]:
+        cfg = wts.config(name, trimmed)
+        W = wts.init_encoder_weights(cfg, seed=0, profile="test")
+        enc = hf_encoder(cfg, W)
+        mel = encoder_mel(cfg, batch)
+        with torch.no_grad():
+            res = enc(torch.from_numpy(mel), output_hidden_states=True)
+        last = res.last_hidden_state.numpy()
+        hs = [h.numpy() for h in res.hidden_states]   # embeddings, then every layer output (pre final LN)
+        key = cfg.name
+        out[f"{key}/weights_sha256"] = np.frombuffer(bytes.fromhex(wts.weights_digest(W)), dtype=np.uint8)
+        out[f"{key}/mel_sum"] = np.float64(mel.astype(np.float64).sum())
+        out[f"{key}/last_sum"] = np.float64(last.astype(np.float64).sum())
+        out[f"{key}/last_head"] = last[:, :4, :]
+        out[f"{key}/last_tail"] = last[:, -4:, :]
+        out[f"{key}/boundary_stats"] = np.array([[h.mean(), h.std(), np.abs(h).max()] for h in hs], dtype=np.float64)
+        out[f"{key}/boundary_head"] = np.stack([h[:, :2, :] for h in hs])
+        if full:
+            out[f"{key}/last_full"] = last
+        print(key, "encoder fixture done", last.shape)
+    # sinusoid rows (fixture F5) from the HF module itself
+    from transformers.models.whisper.modeling_whisper import sinusoids
+    tab = sinusoids(1500, 768).numpy()
+    out["sinusoid_rows_768"] = tab[[0, 1, 199, 1499]]
+    np.savez_compressed(os.path.join(GOLD, "encoder.npz"), **out)
+
+
+def make_pad_tokenizer():
+    """A tokenizer whose only used behaviour is `.pad` (right-pad with Whisper's pad id 50257 + attention mask)."""
+    from tokenizers import Tokenizer
+    from tokenizers.models import WordLevel
+    from transformers import PreTrainedTokenizerFast
+
+    vocab = {f"t{i}": i for i in range(51865)}
+    vocab["<|endoftext|>"] = vocab.pop("t50257")
+    tok = Tokenizer(WordLevel(vocab, unk_token="t0"))
+    return PreTrainedTokenizerFast(tokenizer_object=tok, pad_token="<|endoftext|>")
+
+
+def gen_collator():
+    from transformers import WhisperFeatureExtractor
+
+    processor = types.SimpleNamespace(feature_extractor=WhisperFeatureExtractor(), tokenizer=make_pad_tokenizer())
+    model = types.SimpleNamespace(config=types.SimpleNamespace(decoder_start_token_id=50258))
+    ns = runpy.run_path("/root/reference/AB/exampleDataCollator.py",
+                        init_globals={"torch": torch, "processor": processor, "model": model})
+    collate = ns["data_collator"]
+    out = {}
+    cases = {
+        "bos_all": [[50258, 1, 2, 3], [50258, 4, 5], [50258, 6]],
+        "bos_some": [[50258, 1, 2, 3], [7, 4, 5], [50258, 6]],
+        "single": [[50258, 9, 8, 7, 6, 5]],
+    }
+    for name, labels in cases.items():
+        feats = []
+        for i, lab in enumerate(labels):
+            f = np.full((80, 3000), 0.25 * (i + 1), dtype=np.float32)
+            f[i, i] = -1.0
+            feats.append({"input_features": f, "labels": lab})
+        batch = collate(feats)
+        out[f"{name}/labels"] = batch["labels"].numpy().astype(np.int64)
+        out[f"{name}/input_shape"] = np.array(batch["input_features"].shape, dtype=np.int64)
+        out[f"{name}/input_probe"] = batch["input_features"][:, :4, :4].numpy()
+        assert batch["input_features"].dtype == torch.float32
+    np.savez_compressed(os.path.join(GOLD, "collator.npz"), **out)
+    print("collator fixture written")
+
+
+if __name__ == "__main__":
+    os.makedirs(GOLD, exist_ok=True)
+    what = sys.argv[1:] or ["logmel", "encoder", "collator"]
+    if "logmel" in what:
+        gen_logmel()
+    if "encoder" in what:
+        gen_encoder()
+    if "collator" in what:
+        gen_collator()
