@@ -1,0 +1,150 @@
+/* awt.h -- C-ABI of libawt.so: the MI355X-native (gfx950) log-mel front-end + Whisper-style audio encoder.
+ *
+ * The reference (AdamBeedell/MLX8-WS-Audio-Transformer) has no FFI / plugin interface for this path: it is
+ * reached through ordinary Python call sites into `transformers`.  Each entry point below
+ * names the reference call it stands behind; the Python modules under mlx8-ws-audio-transformer_amd/ wrap them so that those
+ * call sites keep their names, argument meaning and error behaviour (INTEGRATION.md shows the ctypes stub).
+ *
+ * Conventions
+ *  - every function returns AWT_OK (0) or a negative awt_status; nothing throws across the ABI;
+ *    awt_last_error() returns a thread-local message owned by the library;
+ *  - all data pointers are CALLER-OWNED DEVICE pointers (e.g. torch tensors' data_ptr()); the library never
+ *    frees caller memory and never allocates inside a compute call (tables and converted weights are
+ *    allocated in *_create / *_set_weight / first-use of a table size);
+ *  - all work is enqueued on the caller's hipStream_t (passed as void*; NULL = default stream);
+ *    no hidden synchronisation except where a function says so (awt_prof_collect);
+ *  - a handle is not thread-safe; distinct handles are independent; one awt_ctx per (process, device).
+ */
+#ifndef AWT_H_
+#define AWT_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum awt_status {
+  AWT_OK = 0,
+  AWT_ERR_INVALID = -1,      /* bad argument (shape, alignment, NULL, unsupported config)            */
+  AWT_ERR_HIP = -2,          /* a HIP runtime call failed; message carries hipGetErrorString          */
+  AWT_ERR_WORKSPACE = -3,    /* caller's workspace is smaller than *_workspace_bytes()                */
+  AWT_ERR_STATE = -4,        /* weights missing / handle misuse                                       */
+  AWT_ERR_VALUE = -5         /* value error the reference raises too (e.g. mel length != 2*S)         */
+} awt_status;
+
+typedef struct awt_ctx awt_ctx;
+typedef struct awt_encoder awt_encoder;
+
+const char* awt_last_error(void);
+const char* awt_version(void);
+
+int awt_ctx_create(int device, awt_ctx** out);
+void awt_ctx_destroy(awt_ctx* c);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Whisper log-mel (K1-K4).  Stands behind `processor(audio, sampling_rate=16000)` /
+ * `WhisperFeatureExtractor.__call__`:
+ *   /root/reference/AB/fineTune.py:88, AB/wavToWhisper.py:55, AB/fineTuneMidiTester.py:33,
+ *   .charles/music2midi/model.py:100-104 -> HF:models/whisper/feature_extraction_whisper.py:105-168,193-346.
+ * pcm        [B] clips, `pcm_stride` elements apart; int16 (decoded as x/32768, the reference loaders'
+ *            convention) when pcm_is_i16 != 0, else float32.
+ * n_valid    device int32[B] = samples of each clip that are real (rest is zero padding), or NULL = max_valid
+ *            for every clip.  Samples at index >= n_valid[b] are never read.
+ * max_valid  host-side upper bound of n_valid (sizes the grid); clips longer than 160*n_frames_out samples
+ *            are truncated like the reference does (feature_extraction_whisper.py:300-305).
+ * n_frames_out  3000 = the reference's behaviour (clip zero-padded to 30 s); 400 = trimmed 4 s mode.
+ * out        float32 [B, 80, n_frames_out].
+ * workspace  >= awt_logmel_workspace_bytes(B) bytes, 16-byte aligned.
+ */
+size_t awt_logmel_workspace_bytes(int B);
+int awt_logmel_whisper(awt_ctx* c, const void* pcm, int pcm_is_i16, int64_t pcm_stride, const int32_t* n_valid,
+                       int max_valid, int B, int n_frames_out, float* out, void* workspace, size_t ws_bytes,
+                       void* stream);
+
+/* UrbanSound log-mel (K15).  Stands behind `torch.log(mel_spectrogram(waveform) + 1e-6)`:
+ *   /root/reference/.charles/spectrogram.py:79-87,160-162 (torchaudio MelSpectrogram: periodic Hann(n_fft),
+ *   center/reflect, power 2, HTK mel, no norm).
+ * pcm float32 [B] clips of n_samples (already mono / padded / trimmed: spectrogram.py:145-157),
+ * out float32 [B, n_mels, 1 + n_samples / hop].  Supported: n_fft in {400, 512, 1024}, n_mels <= 128. */
+int awt_logmel_generic(awt_ctx* c, const float* pcm, int64_t pcm_stride, int B, int n_samples, int sample_rate,
+                       int n_fft, int hop, int n_mels, float f_min, float f_max, float log_eps, float* out,
+                       void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Whisper-style audio encoder (K5-K13).  Stands behind `encoder(input_features).last_hidden_state`
+ * (`WhisperModel.get_encoder()`, .charles/music2midi/model.py:33,109-110; implicitly AB/fineTune.py:199)
+ * -> HF:models/whisper/modeling_whisper.py:592-646 (+ :379-413, :284-356, :215-238).
+ */
+typedef struct awt_encoder_cfg {
+  int32_t d_model;          /* 384 tiny, 512 base, 768 small; multiple of 128                              */
+  int32_t n_layers;
+  int32_t n_heads;          /* head_dim = d_model / n_heads must be 64                                     */
+  int32_t ffn_dim;          /* multiple of 128                                                             */
+  int32_t n_mels;           /* 80                                                                          */
+  int32_t n_ctx;            /* S = max_source_positions: 1500 (reference) or 200 (trimmed); mel T = 2*S    */
+  int32_t mfma_terms;       /* 1: bf16 operands (fast; ~4e-3 rel-L2 vs fp32); 3: split-bf16 hi+lo operands,
+                               three MFMA products per fragment pair (meets the 1e-3 parity bound)         */
+  int32_t lora_rank;        /* 0 = no adapters; else 1..64                                                 */
+  float lora_alpha;         /* adapter scale = lora_alpha / lora_rank                                      */
+  uint32_t lora_targets;    /* bit mask of AWT_LORA_*                                                      */
+  int32_t chunk_clips;      /* clips processed per kernel wave (0 = library default)                       */
+} awt_encoder_cfg;
+
+enum { AWT_LORA_Q = 1, AWT_LORA_K = 2, AWT_LORA_V = 4, AWT_LORA_OUT = 8, AWT_LORA_FC1 = 16, AWT_LORA_FC2 = 32 };
+
+int awt_encoder_create(awt_ctx* c, const awt_encoder_cfg* cfg, awt_encoder** out);
+void awt_encoder_destroy(awt_encoder* e);
+
+/* Upload one parameter by its HF state-dict key (relative to the encoder module): `conv1.weight`,
+ * `layers.{i}.self_attn.{q,k,v,out}_proj.{weight,bias}`, `layers.{i}.{self_attn_layer_norm,final_layer_norm}.*`,
+ * `layers.{i}.fc{1,2}.*`, `layer_norm.*`, `embed_positions.weight`, plus build-defined `<module>.lora_A` [r, in] and
+ * `<module>.lora_B` [out, r].  `data` is a float32 device pointer of `rank`-d `shape`; the library converts it to
+ * its internal bf16 (hi / lo) layout on `stream` and keeps its own copy. */
+int awt_encoder_set_weight(awt_encoder* e, const char* hf_name, const float* data, const int64_t* shape, int rank,
+                           void* stream);
+
+size_t awt_encoder_workspace_bytes(const awt_encoder* e, int B);
+
+/* input_features float32 [B, n_mels, 2*n_ctx] -> last_hidden_state float32 [B, n_ctx, d_model].
+ * `n_frames` must equal 2*n_ctx, otherwise AWT_ERR_VALUE (the reference raises ValueError,
+ * modeling_whisper.py:612-616). */
+int awt_encoder_forward(awt_encoder* e, const float* input_features, int B, int n_frames, float* last_hidden_state,
+                        void* workspace, size_t ws_bytes, void* stream);
+
+/* PCM -> hidden states in one call (log-mel + encoder, chunked so intermediates stay cache-resident):
+ * the batched form of `WhisperAudioEncoder.forward` (.charles/music2midi/model.py:42-123).
+ * `input_features_out` may be NULL; when given it receives float32 [B, n_mels, 2*n_ctx]. */
+size_t awt_audio_encode_workspace_bytes(const awt_encoder* e, int B);
+int awt_audio_encode(awt_encoder* e, const void* pcm, int pcm_is_i16, int64_t pcm_stride, const int32_t* n_valid,
+                     int max_valid, int B, float* input_features_out, float* last_hidden_state, void* workspace,
+                     size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Single-operator entry points (what the encoder is made of; used by the per-kernel parity tests).
+ * Row-major float32 in / out; bf16 splitting happens inside.  `terms` = 1 or 3 as in awt_encoder_cfg. */
+int awt_op_linear(awt_ctx* c, const float* x /*[M,K]*/, const float* w /*[N,K]*/, const float* bias /*[N] or NULL*/,
+                  float* y /*[M,N]*/, int M, int N, int K, int terms, void* workspace, size_t ws_bytes, void* stream);
+size_t awt_op_linear_workspace_bytes(int M, int N, int K);
+int awt_op_layernorm(awt_ctx* c, const float* x /*[M,d]*/, const float* gamma, const float* beta, float* y, int M, int d,
+                     float eps, void* stream);
+/* q (already scaled), k, v: float32 [B, H, S, 64]; o: float32 [B, S, H*64] */
+int awt_op_attention(awt_ctx* c, const float* q, const float* k, const float* v, float* o, int B, int H, int S,
+                     int terms, void* workspace, size_t ws_bytes, void* stream);
+size_t awt_op_attention_workspace_bytes(int B, int H, int S);
+
+/* ------------------------------------------------------------------------------------------------------
+ * In-library kernel timing with HIP events on the caller's stream (bench.py's `roofline` leg).
+ * awt_prof_enable(c, 1) makes every launch of the kernel classes below record an event pair;
+ * awt_prof_collect synchronises the events and returns accumulated milliseconds and launch count
+ * for one class, then resets that class. */
+enum { AWT_PROF_LOGMEL = 0, AWT_PROF_GEMM = 1, AWT_PROF_ATTENTION = 2, AWT_PROF_LAYERNORM = 3, AWT_PROF_OTHER = 4,
+       AWT_PROF_NCLASSES = 5 };
+int awt_prof_enable(awt_ctx* c, int on);
+int awt_prof_collect(awt_ctx* c, int klass, double* total_ms, int64_t* launches, double* flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AWT_H_ */

@@ -1,0 +1,251 @@
+// Flash-style multi-head self-attention forward (K10) for head_dim 64, no mask -- gfx950.
+//
+//   O[b, s, h, :] = softmax_k( q[b,h,s,:] . k[b,h,k,:] ) v[b,h,k,:]      q is pre-scaled by head_dim^-1/2 in the QKV
+//   epilogue, as the reference scales q BEFORE q k^T (HF:modeling_whisper.py:309, 215-238).
+//
+// Structure (per workgroup: 4 waves x 32 query rows = 128 queries of one (batch, head); K/V tiles of 64 keys):
+//  * "swapped" first product  S^T = K Q^T  on v_mfma_f32_32x32x16_bf16: the 32x32 result has the QUERY on the lane
+//    and 16 keys in registers, so the online-softmax row max / row sum are in-register reductions plus one
+//    cross-half exchange, and the exponentiated tile is directly the B operand of the second product
+//    O^T += V^T P^T  (cdna_hip_programming.md §3 "An accumulator tile as the next MFMA's operand").
+//  * K and V tiles are copied global -> LDS by 16-byte LDS-DMA, double buffered, chunk-XOR-swizzled on the source
+//    address; K fragments are ds_read_b128 rows, V^T fragments come from the hardware transpose read
+//    ds_read_b64_tr_b16 in the permuted key order the P operand has.
+//  * TERMS = 3 runs both products in split-bf16 (q, k, v and P as hi + lo planes, three MFMAs per fragment pair).
+//  * fp32 running max / sum / output accumulators; S = 1500 is not a multiple of 64: tail keys are masked,
+//    tail rows clamped on load and skipped on store.
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int QW = 32;            // queries per wave
+constexpr int QB = 128;           // queries per workgroup
+constexpr int KB = 64;            // keys per tile
+constexpr int PLANE = KB * 64 * 2;  // 8 KiB: [64 keys][64 dims] bf16
+constexpr float kLog2e = 1.4426950408889634f;
+
+struct AttnArgs {
+  const bf16_t *q_hi, *q_lo, *k_hi, *k_lo, *v_hi, *v_lo;
+  bf16_t *o_hi, *o_lo; float* o_f32;
+  int B, H, S;
+};
+
+__device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
+
+__device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int TERMS>
+__device__ __forceinline__ void stage_kv(const AttnArgs& a, int64_t head_off, int kt, char* stage, int wave, int lane) {
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int p = it * kThreads + wave * 64 + lane;
+    const int row = p >> 3;
+    const int c = (p & 7) ^ swz(row);
+    int key = kt * KB + row; key = key < a.S ? key : a.S - 1;
+    const int64_t off = head_off + (int64_t)key * 64 + c * 8;
+    char* dst = stage + (it * kThreads + wave * 64) * 16;
+    glds16(a.k_hi + off, dst);
+    if (TERMS == 3) glds16(a.k_lo + off, dst + PLANE);
+    glds16(a.v_hi + off, dst + (TERMS == 3 ? 2 : 1) * PLANE);
+    if (TERMS == 3) glds16(a.v_lo + off, dst + 3 * PLANE);
+  }
+}
+
+__device__ __forceinline__ bf16x4 tr_read(const char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)p);
+}
+
+template <int TERMS>
+__global__ __launch_bounds__(kThreads, 2) void attention_kernel(AttnArgs a) {
+  constexpr int NPL = TERMS == 3 ? 4 : 2;
+  constexpr int STAGE = NPL * PLANE;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int bh = blockIdx.y;                      // b * H + h
+  const int b = bh / a.H, h = bh - b * a.H;
+  const int q0 = blockIdx.x * QB + wave * QW;
+  const int64_t head_off = (int64_t)bh * a.S * 64;
+  const int ql = lane & 31, half = lane >> 5;
+
+  // ---- Q fragments (B operand of S^T = K Q^T): lane holds Q[q][16 ks + 8 half + j], j = 0..7
+  bf16x8 qh[4], qlo[4];
+  {
+    int q = q0 + ql; q = q < a.S ? q : a.S - 1;
+    const int64_t off = head_off + (int64_t)q * 64 + half * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      qh[ks] = *reinterpret_cast<const bf16x8*>(a.q_hi + off + ks * 16);
+      if (TERMS == 3) qlo[ks] = *reinterpret_cast<const bf16x8*>(a.q_lo + off + ks * 16);
+    }
+  }
+
+  f32x16 oacc[2];
+  oacc[0] = (f32x16){}; oacc[1] = (f32x16){};
+  float m_run = -1.0e30f, l_run = 0.f;   // running max (log2 domain) and this half-wave's partial row sum
+
+  const int ntiles = (a.S + KB - 1) / KB;
+  stage_kv<TERMS>(a, head_off, 0, smem, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const char* cur = smem + (kt & 1) * STAGE;
+    if (kt + 1 < ntiles) stage_kv<TERMS>(a, head_off, kt + 1, smem + ((kt + 1) & 1) * STAGE, wave, lane);
+    const char* k_hi = cur;
+    const char* k_lo = cur + PLANE;
+    const char* v_hi = cur + (TERMS == 3 ? 2 : 1) * PLANE;
+    const char* v_lo = cur + 3 * PLANE;
+
+    // ---- S^T = K Q^T : two 32-key sub-tiles, rows = keys, cols (lanes) = queries
+    f32x16 sacc[2];
+#pragma unroll
+    for (int kt2 = 0; kt2 < 2; ++kt2) {
+      sacc[kt2] = (f32x16){};
+      const int row = kt2 * 32 + ql;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int off = row * 128 + (((2 * ks + half) ^ swz(row)) << 4);
+        const bf16x8 kh = *reinterpret_cast<const bf16x8*>(k_hi + off);
+        if (TERMS == 3) {
+          const bf16x8 kl = *reinterpret_cast<const bf16x8*>(k_lo + off);
+          sacc[kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qlo[ks], sacc[kt2], 0, 0, 0);
+          sacc[kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh[ks], sacc[kt2], 0, 0, 0);
+        }
+        sacc[kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[ks], sacc[kt2], 0, 0, 0);
+      }
+    }
+
+    // ---- online softmax (log2 domain). C/D layout 32x32: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 half
+    const bool tail = (kt + 1) * KB > a.S;
+    float tmax = -1.0e30f;
+#pragma unroll
+    for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float t = sacc[kt2][r] * kLog2e;
+        if (tail) {
+          const int key = kt * KB + kt2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          t = key < a.S ? t : -1.0e30f;
+        }
+        sacc[kt2][r] = t;
+        tmax = fmaxf(tmax, t);
+      }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    const float m_new = fmaxf(m_run, tmax);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.f;
+#pragma unroll
+    for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = __builtin_amdgcn_exp2f(sacc[kt2][r] - m_new);
+        sacc[kt2][r] = pv;
+        psum += pv;
+      }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int et = 0; et < 2; ++et)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[et][r] *= alpha;
+
+    // ---- O^T += V^T P^T : P registers 8 s .. 8 s + 7 of a sub-tile are the B fragment of k-step s;
+    //      element j of lane-half `half` is key 16 s + 8 (j >> 2) + 4 half + (j & 3) of that sub-tile.
+#pragma unroll
+    for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        bf16x8 ph, pl;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          bf16_t hi, lo;
+          split_bf16(sacc[kt2][8 * s + j], hi, lo);
+          ph[j] = (short)hi;
+          if (TERMS == 3) pl[j] = (short)lo;
+        }
+        // V^T fragment via the transpose read: 16-lane group g = lane >> 4 covers dims 16 (g & 1) .. + 15 of the
+        // e-tile for lane-half g >> 1; lane i = 4 qq + pp of the group supplies row (key) qq, columns 4 pp .. 4 pp + 3.
+        const int g = lane >> 4, i = lane & 15, qq = i >> 2, pp = i & 3;
+#pragma unroll
+        for (int et = 0; et < 2; ++et) {
+          const int e0 = 32 * et + 16 * (g & 1);
+          const int key0 = kt2 * 32 + 16 * s + 4 * (g >> 1) + qq;
+          const int chunk = (e0 >> 3) + (pp >> 1);
+          const int off0 = key0 * 128 + ((chunk ^ swz(key0)) << 4) + 8 * (pp & 1);
+          const int key1 = key0 + 8;
+          const int off1 = key1 * 128 + ((chunk ^ swz(key1)) << 4) + 8 * (pp & 1);
+          const bf16x4 va = tr_read(v_hi + off0), vb = tr_read(v_hi + off1);
+          const bf16x8 vh = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
+          if (TERMS == 3) {
+            const bf16x4 la = tr_read(v_lo + off0), lb = tr_read(v_lo + off1);
+            const bf16x8 vl = {la[0], la[1], la[2], la[3], lb[0], lb[1], lb[2], lb[3]};
+            oacc[et] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl, oacc[et], 0, 0, 0);
+            oacc[et] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, oacc[et], 0, 0, 0);
+          }
+          oacc[et] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, oacc[et], 0, 0, 0);
+        }
+      }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // ---- normalise and store: lane holds query (lane & 31), dims (r & 3) + 8 (r >> 2) + 4 half of each e-tile
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = 1.0f / l_tot;
+  const int q = q0 + ql;
+  if (q < a.S) {
+    const int64_t row = ((int64_t)b * a.S + q) * (a.H * 64) + h * 64;
+#pragma unroll
+    for (int et = 0; et < 2; ++et)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int e = 32 * et + 8 * g4 + 4 * half;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = oacc[et][4 * g4 + j] * inv;
+        if (a.o_f32) {
+          *reinterpret_cast<float4*>(a.o_f32 + row + e) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+          bf16_t hi[4], lo[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) split_bf16(v[j], hi[j], lo[j]);
+          *reinterpret_cast<uint2*>(a.o_hi + row + e) = make_uint2(pack2(hi[0], hi[1]), pack2(hi[2], hi[3]));
+          if (a.o_lo) *reinterpret_cast<uint2*>(a.o_lo + row + e) = make_uint2(pack2(lo[0], lo[1]), pack2(lo[2], lo[3]));
+        }
+      }
+  }
+}
+
+template <int TERMS>
+int launch_t(const AttnArgs& a, hipStream_t s) {
+  constexpr int lds = 2 * (TERMS == 3 ? 4 : 2) * PLANE;
+  static bool attr = false;
+  if (!attr) {
+    AWT_HIP_CHECK(hipFuncSetAttribute((const void*)attention_kernel<TERMS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr = true;
+  }
+  dim3 grid((a.S + QB - 1) / QB, a.B * a.H);
+  hipLaunchKernelGGL(attention_kernel<TERMS>, grid, dim3(kThreads), lds, s, a);
+  AWT_HIP_CHECK(hipGetLastError());
+  return AWT_OK;
+}
+
+}  // namespace
+
+int launch_attention(awt_ctx* c, const bf16_t* q_hi, const bf16_t* q_lo, const bf16_t* k_hi, const bf16_t* k_lo,
+                     const bf16_t* v_hi, const bf16_t* v_lo, bf16_t* o_hi, bf16_t* o_lo, float* o_f32, int B, int H,
+                     int S, int terms, hipStream_t s) {
+  AWT_REQUIRE(B > 0 && H > 0 && S > 0, AWT_ERR_INVALID, "attention: bad shape");
+  AWT_REQUIRE(terms == 1 || terms == 3, AWT_ERR_INVALID, "attention: terms must be 1 or 3");
+  AWT_REQUIRE(q_hi && k_hi && v_hi && (o_hi || o_f32), AWT_ERR_INVALID, "attention: null plane");
+  AWT_REQUIRE(terms == 1 || (q_lo && k_lo && v_lo), AWT_ERR_INVALID, "attention: lo planes required for terms == 3");
+  AWT_REQUIRE((int64_t)B * H <= 65535, AWT_ERR_INVALID, "attention: B * H exceeds the grid's y extent");
+  AttnArgs a{q_hi, q_lo, k_hi, k_lo, v_hi, v_lo, o_hi, o_lo, o_f32, B, H, S};
+  ProfScope prof(c, AWT_PROF_ATTENTION, s, 4.0 * (double)B * H * (double)S * S * 64);
+  return terms == 3 ? launch_t<3>(a, s) : launch_t<1>(a, s);
+}

@@ -1,0 +1,126 @@
+// Shared device/host helpers for libawt (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/awt.h"
+
+typedef unsigned short bf16_t;  // raw bfloat16 bits
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+#define AWT_WAVE 64
+
+// ---------------------------------------------------------------- bf16 helpers (device)
+__device__ __forceinline__ bf16_t f32_to_bf16(float x) {
+  // plain cast: hipcc emits v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN stays NaN; MI355X_MICROARCH correctness table)
+  __bf16 b = (__bf16)x;
+  return __builtin_bit_cast(bf16_t, b);
+}
+__device__ __forceinline__ float bf16_to_f32(bf16_t b) {
+  return __builtin_bit_cast(float, ((unsigned)b) << 16);
+}
+// hi + lo split: x ~= hi + lo with |x - hi - lo| <= 2^-17 |x|
+__device__ __forceinline__ void split_bf16(float x, bf16_t& hi, bf16_t& lo) {
+  hi = f32_to_bf16(x);
+  lo = f32_to_bf16(x - bf16_to_f32(hi));
+}
+__device__ __forceinline__ unsigned pack2(bf16_t a, bf16_t b) { return (unsigned)a | ((unsigned)b << 16); }
+
+// exact-erf GELU, as torch.nn.functional.gelu (HF:modeling_whisper.py:618-619, activation_function "gelu")
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// ---------------------------------------------------------------- host-side error plumbing
+void awt_set_error(const std::string& msg);
+int awt_fail(int code, const std::string& msg);
+
+#define AWT_HIP_CHECK(expr)                                                                      \
+  do {                                                                                           \
+    hipError_t _e = (expr);                                                                      \
+    if (_e != hipSuccess)                                                                        \
+      return awt_fail(AWT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));           \
+  } while (0)
+
+#define AWT_REQUIRE(cond, code, msg)         \
+  do {                                       \
+    if (!(cond)) return awt_fail(code, msg); \
+  } while (0)
+
+// ---------------------------------------------------------------- profiling (HIP events on the launch stream)
+struct awt_prof_state;
+struct awt_ctx {
+  int device = 0;
+  int prof_on = 0;
+  awt_prof_state* prof = nullptr;
+  // device-resident constant tables owned by the library, keyed by their parameters
+  struct Table;
+  Table* tables = nullptr;
+};
+
+void awt_prof_begin(awt_ctx* c, int klass, hipStream_t s, double flops);
+void awt_prof_end(awt_ctx* c, int klass, hipStream_t s);
+
+struct ProfScope {
+  awt_ctx* c; int klass; hipStream_t s;
+  ProfScope(awt_ctx* c_, int k, hipStream_t s_, double flops = 0.0) : c(c_), klass(k), s(s_) {
+    if (c && c->prof_on) awt_prof_begin(c, klass, s, flops);
+  }
+  ~ProfScope() { if (c && c->prof_on) awt_prof_end(c, klass, s); }
+};
+
+// ---------------------------------------------------------------- kernel launchers (defined in the .hip files)
+// GEMM:  C[M, N] = sum_seg A_seg[rowmap(m), 0:K_seg] . W_seg[n, 0:K_seg]^T, operands bf16 hi (+ lo when terms == 3)
+struct GemmSeg {
+  const bf16_t* a_hi; const bf16_t* a_lo; int64_t lda;   // activations, K contiguous
+  const bf16_t* w_hi; const bf16_t* w_lo; int64_t ldw;   // weights [N, K_seg], K contiguous
+  int K;                                                 // multiple of the kernel's BK
+  // source row of output row m:  (m / rows_out) * rows_in + (m % rows_out) * row_mul + row_add ; rows outside
+  // [0, rows_in) of their group read as zeros (the conv stem's padding).  Plain GEMM: rows_out = rows_in = M.
+  int rows_out, rows_in, row_mul, row_add;
+};
+
+enum GemmEpilogue {
+  EPI_F32 = 0,        // out_f32[m, n] = acc + bias                        (ldo)
+  EPI_F32_RESID = 1,  // out_f32[m, n] = resid[m, n] + acc + bias          (in place allowed)
+  EPI_BF16 = 2,       // out hi/lo [m, n] = (acc + bias) * scale
+  EPI_BF16_GELU = 3,  // out hi/lo [m, n] = gelu(acc + bias)
+  EPI_QKV = 4,        // head-major q|k|v planes, q columns scaled by `scale`
+  EPI_F32_GELU_POS = 5  // out_f32[m, n] = gelu(acc + bias) + pos[m % rows_pos, n]   (conv2 + positional table)
+};
+
+struct GemmOut {
+  float* f32; const float* resid; int64_t ldo;
+  bf16_t* hi; bf16_t* lo;                 // lo may be null when terms == 1
+  const float* bias;                      // [N] or null
+  const float* pos; int rows_pos;         // EPI_F32_GELU_POS
+  float scale;                            // EPI_BF16: all columns; EPI_QKV: q columns
+  int n_valid;                            // columns >= n_valid are not stored (N padded up to the tile)
+  int S, H;                               // EPI_QKV: m = b * S + s ; plane stride = B*H*S*64
+  int64_t plane_stride;
+};
+
+int launch_gemm(awt_ctx* c, int M, int N, const GemmSeg* segs, int nseg, int terms, GemmEpilogue epi, const GemmOut& out,
+                hipStream_t s);
+
+int launch_layernorm(awt_ctx* c, const float* x, const float* gamma, const float* beta, int M, int d, float eps,
+                     float* out_f32, bf16_t* out_hi, bf16_t* out_lo, hipStream_t s);
+// q, k, v planes: bf16 [B, H, S, 64] (lo may be null for terms == 1); o: bf16 [B*S, H*64] hi/lo
+int launch_attention(awt_ctx* c, const bf16_t* q_hi, const bf16_t* q_lo, const bf16_t* k_hi, const bf16_t* k_lo,
+                     const bf16_t* v_hi, const bf16_t* v_lo, bf16_t* o_hi, bf16_t* o_lo, float* o_f32, int B, int H,
+                     int S, int terms, hipStream_t s);
+int launch_split_f32(awt_ctx* c, const float* x, int64_t n, bf16_t* hi, bf16_t* lo, hipStream_t s);
+// weights: dst[(row_off + n) * ld + col_off + k] = scale * src[n, c, dt], k = dt * C + c (taps = 1: plain [N, C])
+int launch_pack_weight(awt_ctx* c, const float* src, int N, int C, int taps, int64_t ld, int row_off, int col_off, float scale,
+                       bf16_t* hi, bf16_t* lo, hipStream_t s);
+// conv1 im2col: mel f32 [B, C, T] -> A [B*T, K_dst] bf16 hi/lo, k = dt * C + c reads mel[b, c, t + dt - 1]
+int launch_im2col_conv1(awt_ctx* c, const float* mel, int B, int C, int T, int K_dst, bf16_t* hi, bf16_t* lo, hipStream_t s);
+
+int logmel_whisper_impl(awt_ctx* c, const void* pcm, int pcm_is_i16, int64_t pcm_stride, const int32_t* n_valid,
+                        int max_valid, int B, int n_frames_out, float* out, void* workspace, size_t ws_bytes, hipStream_t s);
+int logmel_generic_impl(awt_ctx* c, const float* pcm, int64_t pcm_stride, int B, int n_samples, int sample_rate, int n_fft,
+                        int hop, int n_mels, float f_min, float f_max, float log_eps, float* out, hipStream_t s);
+void awt_free_tables(awt_ctx* c);

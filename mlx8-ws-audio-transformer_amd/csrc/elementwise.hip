@@ -1,0 +1,170 @@
+// HBM-bound row kernels of the encoder: LayerNorm (K8), fp32 -> split-bf16 planes, weight packing, conv1 im2col.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ LayerNorm
+// One wave per row, the row lives in registers (d <= 1024): two-pass mean / variance in fp32 exactly like
+// torch.nn.functional.layer_norm (eps 1e-5, biased variance; HF:modeling_whisper.py:392,402,642), then affine.
+// Output is either fp32 (final layer_norm -> last_hidden_state) or bf16 hi (+ lo) planes for the next GEMM.
+constexpr int kLnMaxChunks = 4;  // float4 chunks per lane: d <= 64 * 4 * 4
+
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, int M, int d, float eps,
+                                                        float* out_f32, bf16_t* out_hi, bf16_t* out_lo) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nchunk = d >> 2;
+  const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * d);
+  float4 v[kLnMaxChunks];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < kLnMaxChunks; ++i) {
+    const int c = lane + 64 * i;
+    v[i] = c < nchunk ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  const float mean = sum / (float)d;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < kLnMaxChunks; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunk) {
+      const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, dd = v[i].w - mean;
+      sq += (a * a + b * b) + (cc * cc + dd * dd);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+  const float rstd = 1.0f / sqrtf(sq / (float)d + eps);
+  const float4* g4 = reinterpret_cast<const float4*>(gamma);
+  const float4* b4 = reinterpret_cast<const float4*>(beta);
+#pragma unroll
+  for (int i = 0; i < kLnMaxChunks; ++i) {
+    const int c = lane + 64 * i;
+    if (c >= nchunk) continue;
+    const float4 g = g4[c], bb = b4[c];
+    float y[4] = {(v[i].x - mean) * rstd * g.x + bb.x, (v[i].y - mean) * rstd * g.y + bb.y,
+                  (v[i].z - mean) * rstd * g.z + bb.z, (v[i].w - mean) * rstd * g.w + bb.w};
+    if (out_f32) {
+      reinterpret_cast<float4*>(out_f32 + (int64_t)row * d)[c] = make_float4(y[0], y[1], y[2], y[3]);
+    } else {
+      bf16_t hi[4], lo[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) split_bf16(y[j], hi[j], lo[j]);
+      reinterpret_cast<uint2*>(out_hi + (int64_t)row * d)[c] = make_uint2(pack2(hi[0], hi[1]), pack2(hi[2], hi[3]));
+      if (out_lo) reinterpret_cast<uint2*>(out_lo + (int64_t)row * d)[c] = make_uint2(pack2(lo[0], lo[1]), pack2(lo[2], lo[3]));
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ fp32 -> hi / lo planes
+__global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ x, int64_t n4, bf16_t* hi, bf16_t* lo) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    bf16_t h[4], l[4];
+    split_bf16(v.x, h[0], l[0]); split_bf16(v.y, h[1], l[1]); split_bf16(v.z, h[2], l[2]); split_bf16(v.w, h[3], l[3]);
+    reinterpret_cast<uint2*>(hi)[i] = make_uint2(pack2(h[0], h[1]), pack2(h[2], h[3]));
+    if (lo) reinterpret_cast<uint2*>(lo)[i] = make_uint2(pack2(l[0], l[1]), pack2(l[2], l[3]));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ weight packing
+// dst[(row_off + n) * ld + col_off + k] = src[n, c, dt] * scale with k = dt * C + c  (conv weights [N, C, taps] ->
+// K-contiguous implicit-GEMM rows; taps = 1 is a plain [N, C] linear weight).  Only the N x (C * taps) region is
+// written: destination buffers are zero-initialised at creation, which provides every padding row / column.
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ src, int N, int C, int taps, int64_t ld,
+                                                          int row_off, int col_off, float scale, bf16_t* hi, bf16_t* lo) {
+  const int K = C * taps;
+  const int64_t total = (int64_t)N * K;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i / K), k = (int)(i - (int64_t)n * K);
+    const int dt = k / C, c = k - dt * C;
+    const float v = src[((int64_t)n * C + c) * taps + dt] * scale;
+    bf16_t h, l; split_bf16(v, h, l);
+    const int64_t o = (int64_t)(row_off + n) * ld + col_off + k;
+    hi[o] = h;
+    if (lo) lo[o] = l;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ conv1 im2col
+// mel fp32 [B, C, T] -> A [B * T, K_dst] bf16 planes with A[(b, t), dt * C + c] = mel[b, c, t + dt - 1] (zero outside
+// the clip: Conv1d padding = 1, HF:modeling_whisper.py:566).  A 64-frame slab of the clip is staged in LDS with
+// reads coalesced along t; rows are written as whole 16-byte groups so each row is one contiguous K_dst * 2 B store.
+constexpr int kImTile = 64;
+__global__ __launch_bounds__(256) void im2col_conv1_kernel(const float* __restrict__ mel, int C, int T, int K_dst, bf16_t* hi,
+                                                           bf16_t* lo) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* tile = reinterpret_cast<float*>(smem);   // [C][kImTile + 2], pitch kImTile + 3 (odd: conflict-free column reads)
+  const int pitch = kImTile + 3;
+  const int b = blockIdx.y, t0 = blockIdx.x * kImTile;
+  const float* mb = mel + (int64_t)b * C * T;
+  for (int i = threadIdx.x; i < C * (kImTile + 2); i += 256) {
+    const int c = i / (kImTile + 2), tt = i - c * (kImTile + 2);
+    const int t = t0 + tt - 1;
+    tile[c * pitch + tt] = (t >= 0 && t < T) ? mb[(int64_t)c * T + t] : 0.f;
+  }
+  __syncthreads();
+  const int groups = K_dst / 8;
+  const int cg = C / 8;  // C is a multiple of 8 (80), so a group of 8 never straddles a tap
+  for (int i = threadIdx.x; i < kImTile * groups; i += 256) {
+    const int tl = i / groups, g = i - tl * groups;
+    const int t = t0 + tl;
+    if (t >= T) continue;
+    const int dt = g / cg, c0 = (g - dt * cg) * 8;
+    bf16_t h[8], l[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float v = dt < 3 ? tile[(c0 + j) * pitch + tl + dt] : 0.f;
+      split_bf16(v, h[j], l[j]);
+    }
+    const int64_t off = ((int64_t)b * T + t) * K_dst + g * 8;
+    *reinterpret_cast<uint4*>(hi + off) = make_uint4(pack2(h[0], h[1]), pack2(h[2], h[3]), pack2(h[4], h[5]), pack2(h[6], h[7]));
+    if (lo) *reinterpret_cast<uint4*>(lo + off) = make_uint4(pack2(l[0], l[1]), pack2(l[2], l[3]), pack2(l[4], l[5]), pack2(l[6], l[7]));
+  }
+}
+
+}  // namespace
+
+int launch_layernorm(awt_ctx* c, const float* x, const float* gamma, const float* beta, int M, int d, float eps,
+                     float* out_f32, bf16_t* out_hi, bf16_t* out_lo, hipStream_t s) {
+  AWT_REQUIRE(x && gamma && beta && (out_f32 || out_hi), AWT_ERR_INVALID, "layernorm: null argument");
+  AWT_REQUIRE(M > 0 && d > 0 && d % 4 == 0 && d <= 64 * 4 * kLnMaxChunks, AWT_ERR_INVALID, "layernorm: d must be a multiple of 4 and <= 1024");
+  ProfScope prof(c, AWT_PROF_LAYERNORM, s, 0.0);
+  hipLaunchKernelGGL(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, gamma, beta, M, d, eps, out_f32, out_hi, out_lo);
+  AWT_HIP_CHECK(hipGetLastError());
+  return AWT_OK;
+}
+
+int launch_split_f32(awt_ctx* c, const float* x, int64_t n, bf16_t* hi, bf16_t* lo, hipStream_t s) {
+  AWT_REQUIRE(x && hi && n > 0 && n % 4 == 0, AWT_ERR_INVALID, "split: n must be a positive multiple of 4");
+  ProfScope prof(c, AWT_PROF_OTHER, s, 0.0);
+  const int64_t n4 = n / 4;
+  int grid = (int)((n4 + 255) / 256); if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(split_kernel, dim3(grid), dim3(256), 0, s, x, n4, hi, lo);
+  AWT_HIP_CHECK(hipGetLastError());
+  return AWT_OK;
+}
+
+int launch_pack_weight(awt_ctx* c, const float* src, int N, int C, int taps, int64_t ld, int row_off, int col_off, float scale,
+                       bf16_t* hi, bf16_t* lo, hipStream_t s) {
+  AWT_REQUIRE(src && hi && N > 0 && C > 0 && taps > 0 && ld >= col_off + (int64_t)C * taps, AWT_ERR_INVALID, "pack_weight: bad shape");
+  const int64_t total = (int64_t)N * C * taps;
+  int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(grid), dim3(256), 0, s, src, N, C, taps, ld, row_off, col_off, scale, hi, lo);
+  AWT_HIP_CHECK(hipGetLastError());
+  return AWT_OK;
+}
+
+int launch_im2col_conv1(awt_ctx* c, const float* mel, int B, int C, int T, int K_dst, bf16_t* hi, bf16_t* lo, hipStream_t s) {
+  AWT_REQUIRE(mel && hi && B > 0 && C > 0 && C % 8 == 0 && T > 0 && K_dst % 8 == 0 && K_dst >= 3 * C, AWT_ERR_INVALID, "im2col: bad shape");
+  ProfScope prof(c, AWT_PROF_OTHER, s, 0.0);
+  const size_t lds = (size_t)C * (kImTile + 3) * sizeof(float);
+  hipLaunchKernelGGL(im2col_conv1_kernel, dim3((T + kImTile - 1) / kImTile, B), dim3(256), lds, s, mel, C, T, K_dst, hi, lo);
+  AWT_HIP_CHECK(hipGetLastError());
+  return AWT_OK;
+}

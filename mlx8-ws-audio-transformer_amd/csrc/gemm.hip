@@ -1,0 +1,260 @@
+// bf16 MFMA GEMM with fused epilogues for the encoder's dense contractions (K5, K6, K9, K11, K12, K13) -- gfx950.
+//
+//   C[M, N] = sum over K-segments  A_seg[rowmap(m), :] . W_seg[n, :]^T       (both operands K-contiguous)
+//
+// * operands are bf16 "hi" planes, optionally with "lo" planes (x = hi + lo, |x - hi - lo| <= 2^-17 |x|).
+//   TERMS = 1: acc += a_hi b_hi.  TERMS = 3: acc += a_hi b_lo + a_lo b_hi + a_hi b_hi  (split-bf16: the mode
+//   that meets the 1e-3 hidden-state parity bound; DESIGN.md "Numerics").  Accumulation is always fp32 MFMA.
+// * K-segments let one kernel serve: plain linears (1 segment), linears with a LoRA term
+//   ([x | u] . [W | B]^T, 2 segments) and the stride-2 conv stem as an implicit GEMM (3 taps = 3 segments whose
+//   source row is 2 s + tap - 1, rows outside the clip reading as zero).
+// * 128 x 128 block tile, 4 waves (2 x 2), each wave 64 x 64 = 4 x 4 tiles of v_mfma_f32_16x16x32_bf16.
+//   Tiles are staged global -> LDS with 16-byte LDS-DMA (global_load_lds_dwordx4), double buffered, one barrier per
+//   K-tile; LDS rows are XOR-swizzled on the SOURCE address (the DMA writes LDS linearly) and on the ds_read_b128,
+//   so fragment reads are bank-conflict free.
+// * 1-D grid with an XCD-aware remap: consecutive tiles of one A row-panel run on one XCD so the panel is fetched
+//   from HBM once and then served by that XCD's L2.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, kThreads = 256;
+constexpr int kMaxSeg = 3;
+
+struct GemmArgs {
+  int M, N, nseg, tiles_m, tiles_n;
+  GemmSeg seg[kMaxSeg];
+  GemmOut out;
+  const bf16_t* zeros;   // >= 128 zero bytes (padding rows of the conv stem)
+};
+
+template <int BK> __device__ __forceinline__ int swz(int row);
+// BK = 64: 128-byte rows, 8 chunks of 16 B; BK = 32: 64-byte rows, 4 chunks.  See DESIGN.md "LDS images".
+template <> __device__ __forceinline__ int swz<64>(int row) { return (row >> 1) & 7; }
+template <> __device__ __forceinline__ int swz<32>(int row) { return (0x1320 >> (((row >> 2) & 3) * 4)) & 3; }  // {0,2,3,1}
+
+template <int TERMS, int BK>
+struct Tile {
+  static constexpr int NPL = (TERMS == 3) ? 4 : 2;          // planes per stage: A_hi, (A_lo), W_hi, (W_lo)
+  static constexpr int PLANE = 128 * BK * 2;                // bytes
+  static constexpr int STAGE = NPL * PLANE;
+  static constexpr int CPR = BK / 8;                        // 16-byte chunks per row
+  static constexpr int ITERS = (128 * CPR) / kThreads;      // LDS-DMA instructions per thread per plane
+};
+
+__device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// Per-thread staging state: the rows a thread copies are the same for every K-tile, so the (row-mapped) source
+// pointers are computed once per K-segment and only advanced by BK elements per K-tile.
+template <int TERMS, int BK>
+struct Stager {
+  using T = Tile<TERMS, BK>;
+  const bf16_t* a_hi[T::ITERS]; const bf16_t* a_lo[T::ITERS];
+  const bf16_t* w_hi[T::ITERS]; const bf16_t* w_lo[T::ITERS];
+  int si, kk, nk;
+
+  __device__ __forceinline__ void open_segment(const GemmArgs& g, int seg, int m0, int n0, int wave, int lane) {
+    si = seg; kk = 0;
+    const GemmSeg& sg = g.seg[seg];
+    nk = sg.K / BK;
+#pragma unroll
+    for (int it = 0; it < T::ITERS; ++it) {
+      const int p = it * kThreads + wave * 64 + lane;           // linear 16-byte slot in the plane
+      const int row = p / T::CPR;
+      const int c = (p % T::CPR) ^ swz<BK>(row);                // source chunk that lands in this slot
+      int m = m0 + row; m = m < g.M ? m : g.M - 1;              // M tail: clamp (never stored)
+      const int grp = m / sg.rows_out, r = m - grp * sg.rows_out;
+      const int sr = r * sg.row_mul + sg.row_add;               // conv stem: 2 s + tap - 1
+      const bool ok = (sr >= 0) && (sr < sg.rows_in);
+      const int64_t aoff = ((int64_t)grp * sg.rows_in + sr) * sg.lda + c * 8;
+      a_hi[it] = ok ? sg.a_hi + aoff : nullptr;
+      a_lo[it] = (ok && TERMS == 3) ? sg.a_lo + aoff : nullptr;
+      const int64_t woff = (int64_t)(n0 + row) * sg.ldw + c * 8;
+      w_hi[it] = sg.w_hi + woff;
+      w_lo[it] = (TERMS == 3) ? sg.w_lo + woff : nullptr;
+    }
+  }
+  // copy the current K-tile into `stage_base`, then step to the next K-tile (opening the next segment if needed)
+  __device__ __forceinline__ void stage_and_advance(const GemmArgs& g, char* stage_base, int m0, int n0, int wave, int lane) {
+    const int koff = kk * BK;
+#pragma unroll
+    for (int it = 0; it < T::ITERS; ++it) {
+      char* dst = stage_base + (it * kThreads + wave * 64) * 16;
+      glds16(a_hi[it] ? (const void*)(a_hi[it] + koff) : (const void*)g.zeros, dst);
+      if (TERMS == 3) glds16(a_lo[it] ? (const void*)(a_lo[it] + koff) : (const void*)g.zeros, dst + T::PLANE);
+      glds16(w_hi[it] + koff, dst + (TERMS == 3 ? 2 : 1) * T::PLANE);
+      if (TERMS == 3) glds16(w_lo[it] + koff, dst + 3 * T::PLANE);
+    }
+    if (++kk == nk && si + 1 < g.nseg) open_segment(g, si + 1, m0, n0, wave, lane);
+  }
+};
+
+template <int EPI>
+__device__ __forceinline__ void store_out(const GemmOut& o, int m, int n, float acc, int M) {
+  if (m >= M || n >= o.n_valid) return;
+  float v = acc + (o.bias ? o.bias[n] : 0.f);
+  if (EPI == EPI_F32) {
+    o.f32[(int64_t)m * o.ldo + n] = v;
+  } else if (EPI == EPI_F32_RESID) {
+    o.f32[(int64_t)m * o.ldo + n] = o.resid[(int64_t)m * o.ldo + n] + v;
+  } else if (EPI == EPI_F32_GELU_POS) {
+    o.f32[(int64_t)m * o.ldo + n] = gelu_erf(v) + o.pos[(int64_t)(m % o.rows_pos) * o.ldo + n];
+  } else if (EPI == EPI_BF16 || EPI == EPI_BF16_GELU) {
+    v = (EPI == EPI_BF16_GELU) ? gelu_erf(v) : v * o.scale;
+    bf16_t hi, lo; split_bf16(v, hi, lo);
+    o.hi[(int64_t)m * o.ldo + n] = hi;
+    if (o.lo) o.lo[(int64_t)m * o.ldo + n] = lo;
+  } else if (EPI == EPI_QKV) {
+    const int d = o.H * 64;
+    const int which = n / d, within = n - which * d;
+    const int h = within >> 6, e = within & 63;
+    const int b = m / o.S, s = m - b * o.S;
+    if (which == 0) v *= o.scale;
+    bf16_t hi, lo; split_bf16(v, hi, lo);
+    const int64_t off = (int64_t)which * o.plane_stride + (((int64_t)b * o.H + h) * o.S + s) * 64 + e;
+    o.hi[off] = hi;
+    if (o.lo) o.lo[off] = lo;
+  }
+}
+
+template <int TERMS, int BK, int EPI>
+__global__ __launch_bounds__(kThreads, 2) void gemm_kernel(GemmArgs g) {
+  using T = Tile<TERMS, BK>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+  // XCD-aware bijective remap: hardware deals block b to XCD b % 8; give each XCD a contiguous run of tiles
+  const int nwg = g.tiles_m * g.tiles_n;
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int q = nwg >> 3, r = nwg & 7;
+  const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  int ktiles = 0;
+  for (int s = 0; s < g.nseg; ++s) ktiles += g.seg[s].K / BK;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int wr = wave >> 1, wc = wave & 1;
+  const int frow = lane & 15, fq = lane >> 4;
+
+  Stager<TERMS, BK> st;
+  st.open_segment(g, 0, m0, n0, wave, lane);
+  st.stage_and_advance(g, smem, m0, n0, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int kt = 0; kt < ktiles; ++kt) {
+    char* cur = smem + (kt & 1) * T::STAGE;
+    if (kt + 1 < ktiles) st.stage_and_advance(g, smem + ((kt + 1) & 1) * T::STAGE, m0, n0, wave, lane);
+    const char* a_hi = cur;
+    const char* a_lo = cur + T::PLANE;
+    const char* w_hi = cur + (TERMS == 3 ? 2 : 1) * T::PLANE;
+    const char* w_lo = cur + 3 * T::PLANE;
+#pragma unroll
+    for (int ks = 0; ks < BK / 32; ++ks) {
+      bf16x8 ah[4], bh[4], al[4], bl[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = wr * 64 + i * 16 + frow;
+        const int off = row * (BK * 2) + (((ks * 4 + fq) ^ swz<BK>(row)) << 4);
+        ah[i] = *reinterpret_cast<const bf16x8*>(a_hi + off);
+        if (TERMS == 3) al[i] = *reinterpret_cast<const bf16x8*>(a_lo + off);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = wc * 64 + j * 16 + frow;
+        const int off = row * (BK * 2) + (((ks * 4 + fq) ^ swz<BK>(row)) << 4);
+        bh[j] = *reinterpret_cast<const bf16x8*>(w_hi + off);
+        if (TERMS == 3) bl[j] = *reinterpret_cast<const bf16x8*>(w_lo + off);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (TERMS == 3) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // epilogue: C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int m = m0 + wr * 64 + i * 16 + fq * 4 + rr;
+        const int n = n0 + wc * 64 + j * 16 + frow;
+        store_out<EPI>(g.out, m, n, acc[i][j][rr], g.M);
+      }
+}
+
+template <int TERMS, int BK, int EPI>
+int launch_one(const GemmArgs& a, hipStream_t s) {
+  using T = Tile<TERMS, BK>;
+  static bool attr = false;
+  if (!attr) {
+    AWT_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_kernel<TERMS, BK, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * T::STAGE));
+    attr = true;
+  }
+  hipLaunchKernelGGL((gemm_kernel<TERMS, BK, EPI>), dim3(a.tiles_m * a.tiles_n), dim3(kThreads), 2 * T::STAGE, s, a);
+  AWT_HIP_CHECK(hipGetLastError());
+  return AWT_OK;
+}
+
+template <int EPI>
+int launch_epi(const GemmArgs& a, int terms, hipStream_t s) {
+  return terms == 3 ? launch_one<3, 32, EPI>(a, s) : launch_one<1, 64, EPI>(a, s);
+}
+
+bf16_t* g_zeros = nullptr;
+
+}  // namespace
+
+int launch_gemm(awt_ctx* c, int M, int N, const GemmSeg* segs, int nseg, int terms, GemmEpilogue epi, const GemmOut& out,
+                hipStream_t s) {
+  AWT_REQUIRE(M > 0 && N > 0 && N % BN == 0, AWT_ERR_INVALID, "gemm: N must be a positive multiple of 128");
+  AWT_REQUIRE(nseg >= 1 && nseg <= kMaxSeg, AWT_ERR_INVALID, "gemm: 1..3 K-segments");
+  AWT_REQUIRE(terms == 1 || terms == 3, AWT_ERR_INVALID, "gemm: terms must be 1 or 3");
+  if (!g_zeros) {
+    AWT_HIP_CHECK(hipMalloc((void**)&g_zeros, 256));
+    AWT_HIP_CHECK(hipMemset(g_zeros, 0, 256));
+  }
+  GemmArgs a{};
+  a.M = M; a.N = N; a.nseg = nseg; a.tiles_m = (M + BM - 1) / BM; a.tiles_n = N / BN; a.out = out; a.zeros = g_zeros;
+  double ksum = 0;
+  for (int i = 0; i < nseg; ++i) {
+    a.seg[i] = segs[i];
+    AWT_REQUIRE(segs[i].K > 0 && segs[i].K % 64 == 0, AWT_ERR_INVALID, "gemm: every K-segment must be a positive multiple of 64");
+    AWT_REQUIRE(segs[i].a_hi && segs[i].w_hi && (terms == 1 || (segs[i].a_lo && segs[i].w_lo)), AWT_ERR_INVALID, "gemm: null operand plane");
+    AWT_REQUIRE(segs[i].lda % 8 == 0 && segs[i].ldw % 8 == 0, AWT_ERR_INVALID, "gemm: leading dimensions must be multiples of 8 elements");
+    AWT_REQUIRE(segs[i].rows_out > 0 && segs[i].rows_in > 0, AWT_ERR_INVALID, "gemm: bad row map");
+    ksum += segs[i].K;
+  }
+  ProfScope prof(c, AWT_PROF_GEMM, s, 2.0 * (double)M * (double)out.n_valid * ksum);
+  switch (epi) {
+    case EPI_F32: return launch_epi<EPI_F32>(a, terms, s);
+    case EPI_F32_RESID: return launch_epi<EPI_F32_RESID>(a, terms, s);
+    case EPI_BF16: return launch_epi<EPI_BF16>(a, terms, s);
+    case EPI_BF16_GELU: return launch_epi<EPI_BF16_GELU>(a, terms, s);
+    case EPI_QKV: return launch_epi<EPI_QKV>(a, terms, s);
+    case EPI_F32_GELU_POS: return launch_epi<EPI_F32_GELU_POS>(a, terms, s);
+  }
+  return awt_fail(AWT_ERR_INVALID, "gemm: unknown epilogue");
+}

@@ -1,0 +1,185 @@
+"""`NativeWhisperEncoder`: the reference's encoder call surface over the HIP encoder in libawt.
+
+Reference interface kept:
+* `encoder(input_features) -> obj.last_hidden_state` [B, 1500, d]; reachable as `WhisperModel.get_encoder()`
+      /root/reference/.charles/music2midi/model.py:33,109-110 ; implicitly /root/reference/AB/fineTune.py:199
+* it is an `nn.Module` with `.parameters()`, `.eval()`, `.config.d_model`, `.device` (model.py:37-40,105,120,227)
+* `ValueError` when the mel length is not 2 * max_source_positions; `attention_mask` accepted and ignored
+      HF:models/whisper/modeling_whisper.py:607-616
+* parameters carry the HF state-dict keys (`conv1.weight`, `layers.0.self_attn.q_proj.weight`, ...), so a locally
+  present Whisper checkpoint's encoder state dict loads with `load_state_dict`; LoRA adds `<module>.lora_A/B`.
+
+All arithmetic is in libawt (`awt_encoder_forward`); this class only owns the fp32 master parameters and pushes
+them to the library when they change.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from types import SimpleNamespace
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .weights import EncoderConfig, LoraSpec, encoder_param_shapes, init_encoder_weights, init_lora_weights, lora_param_shapes
+
+PRECISIONS = {"bf16": 1, "bf16x3": 3}
+
+
+@dataclass
+class BaseModelOutput:
+    last_hidden_state: torch.Tensor
+    hidden_states: Optional[tuple] = None
+    attentions: Optional[tuple] = None
+
+    def __getitem__(self, i):
+        return (self.last_hidden_state,)[i]
+
+
+class _Leaf(nn.Module):
+    """Parameter holder so that state-dict keys read `<path>.weight` / `.bias` / `.lora_A` / `.lora_B`."""
+
+
+def _attach(root: nn.Module, dotted: str, p: nn.Parameter) -> None:
+    parts = dotted.split(".")
+    mod = root
+    for name in parts[:-1]:
+        if not hasattr(mod, name):
+            mod.add_module(name, _Leaf())
+        mod = getattr(mod, name)
+    mod.register_parameter(parts[-1], p)
+
+
+class NativeWhisperEncoder(nn.Module):
+    def __init__(self, cfg: EncoderConfig, precision: str = "bf16x3", lora: Optional[LoraSpec] = None,
+                 device: str = "cuda", chunk_clips: int = 0, seed: Optional[int] = 0, init_profile: str = "hf"):
+        super().__init__()
+        if precision not in PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(PRECISIONS)}")
+        if cfg.head_dim != 64:
+            raise ValueError("the native attention kernel is specialised for head_dim 64 (every Whisper size)")
+        self.cfg = cfg
+        self.precision = precision
+        self.lora = lora
+        self.config = SimpleNamespace(d_model=cfg.d_model, encoder_layers=cfg.layers, encoder_attention_heads=cfg.heads,
+                                      encoder_ffn_dim=cfg.ffn, num_mel_bins=cfg.n_mels,
+                                      max_source_positions=cfg.max_source_positions)
+        dev = torch.device(device)
+        base = init_encoder_weights(cfg, seed or 0, init_profile) if seed is not None else None
+        for name, shape in encoder_param_shapes(cfg):
+            t = torch.from_numpy(base[name]) if base is not None else torch.zeros(shape)
+            _attach(self, name, nn.Parameter(t.to(dev), requires_grad=False))
+        if lora is not None:
+            lw = init_lora_weights(cfg, lora, seed or 0) if seed is not None else None
+            for name, shape in lora_param_shapes(cfg, lora):
+                t = torch.from_numpy(lw[name]) if lw is not None else torch.zeros(shape)
+                _attach(self, name, nn.Parameter(t.to(dev), requires_grad=True))
+        self._handle = None
+        self._chunk = chunk_clips
+        self._synced: Dict[str, int] = {}
+        self._ws: Optional[torch.Tensor] = None
+
+    # ------------------------------------------------------------------------------------------------ plumbing
+    @property
+    def device(self) -> torch.device:
+        return next(self.parameters()).device
+
+    @property
+    def dtype(self) -> torch.dtype:
+        return torch.float32
+
+    def get_input_embeddings(self):
+        return self.conv1
+
+    def _ensure_handle(self):
+        if self._handle is not None:
+            return
+        L = _lib.lib()
+        bits = 0
+        if self.lora is not None:
+            for t in self.lora.targets:
+                bits |= _lib.LORA_BITS[t]
+        cfg = _lib.EncoderCfg(self.cfg.d_model, self.cfg.layers, self.cfg.heads, self.cfg.ffn, self.cfg.n_mels,
+                              self.cfg.max_source_positions, PRECISIONS[self.precision],
+                              self.lora.r if self.lora else 0, float(self.lora.alpha) if self.lora else 0.0, bits, self._chunk)
+        out = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(L.awt_encoder_create(_lib.ctx(self.device), C.byref(cfg), C.byref(out)))
+        self._handle = out.value
+
+    def sync_weights(self, force: bool = False) -> int:
+        """Push every parameter that changed since the last push (tracked by tensor version) to the library."""
+        self._ensure_handle()
+        L = _lib.lib()
+        n = 0
+        with torch.cuda.device(self.device):
+            for name, p in self.named_parameters():
+                ver = p._version
+                if not force and self._synced.get(name) == ver:
+                    continue
+                t = p.detach()
+                if t.dtype != torch.float32 or not t.is_contiguous():
+                    t = t.float().contiguous()
+                shape = (C.c_int64 * t.dim())(*t.shape)
+                _lib.check(L.awt_encoder_set_weight(self._handle, name.encode(), _lib.ptr(t), shape, t.dim(), _lib.stream_handle()))
+                self._synced[name] = ver
+                n += 1
+        return n
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        res = super().load_state_dict(state_dict, strict=strict, **kw)
+        self._synced.clear()
+        return res
+
+    def _workspace(self, nbytes: int) -> torch.Tensor:
+        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != self.device:
+            self._ws = _lib.workspace(nbytes, self.device)
+        return self._ws
+
+    def __del__(self):
+        try:
+            if self._handle is not None:
+                _lib.lib().awt_encoder_destroy(self._handle)
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------------------------------------ forward
+    def forward(self, input_features: torch.Tensor, attention_mask=None, **kwargs) -> BaseModelOutput:
+        if input_features.dim() != 3 or input_features.shape[1] != self.cfg.n_mels:
+            raise ValueError(f"input_features must be [B, {self.cfg.n_mels}, T]")
+        x = input_features.to(device=self.device, dtype=torch.float32).contiguous()
+        B, _, T = x.shape
+        self.sync_weights()
+        L = _lib.lib()
+        ws = self._workspace(L.awt_encoder_workspace_bytes(self._handle, B))
+        out = torch.empty((B, self.cfg.max_source_positions, self.cfg.d_model), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(L.awt_encoder_forward(self._handle, _lib.ptr(x), B, T, _lib.ptr(out), _lib.ptr(ws), ws.numel(),
+                                             _lib.stream_handle()))
+        return BaseModelOutput(last_hidden_state=out)
+
+    def encode_pcm(self, pcm: torch.Tensor, n_valid: Optional[torch.Tensor] = None, max_valid: Optional[int] = None,
+                   return_features: bool = False):
+        """Device PCM [B, n] (int16 / float32) -> last_hidden_state [B, S, d] (and input_features if asked): log-mel and
+        encoder in one library call (`awt_audio_encode`), no host round trip."""
+        if pcm.dim() != 2 or pcm.dtype not in (torch.int16, torch.float32) or not pcm.is_cuda:
+            raise ValueError("pcm must be a [B, n] int16 or float32 device tensor")
+        pcm = pcm.contiguous()
+        B, n = pcm.shape
+        max_valid = n if max_valid is None else int(max_valid)
+        if n_valid is not None:
+            n_valid = n_valid.to(device=pcm.device, dtype=torch.int32).contiguous()
+        self.sync_weights()
+        L = _lib.lib()
+        ws = self._workspace(L.awt_audio_encode_workspace_bytes(self._handle, B))
+        S, d, T = self.cfg.max_source_positions, self.cfg.d_model, self.cfg.n_frames
+        out = torch.empty((B, S, d), dtype=torch.float32, device=pcm.device)
+        feats = torch.empty((B, self.cfg.n_mels, T), dtype=torch.float32, device=pcm.device) if return_features else None
+        with torch.cuda.device(pcm.device):
+            _lib.check(L.awt_audio_encode(self._handle, _lib.ptr(pcm), int(pcm.dtype == torch.int16), pcm.stride(0),
+                                          _lib.ptr(n_valid), max_valid, B, _lib.ptr(feats), _lib.ptr(out), _lib.ptr(ws),
+                                          ws.numel(), _lib.stream_handle()))
+        return (out, feats) if return_features else out

@@ -1,0 +1,104 @@
+"""UrbanSound8K front-end and dataset, mirroring /root/reference/.charles/spectrogram.py.
+
+* module constants `SAMPLE_RATE, N_MELS, N_FFT, HOP_LENGTH, FMIN, FMAX, DURATION` read from the environment with
+  the reference's defaults (spectrogram.py:56-62);
+* `mel_spectrogram_log(waveform)`  = `torch.log(mel_spectrogram(waveform) + 1e-6)` (spectrogram.py:79-87,160-162),
+  computed by libawt's `awt_logmel_generic` (periodic Hann, center / reflect, power 2, HTK mel, no norm);
+* `prepare_waveform` = mono mean + pad / trim to DURATION (spectrogram.py:145-157; resampling is out of scope);
+* `UrbanSoundDataSet(parquet_path=None, folds=None)` with `.df`, `.n_mels`, `__len__`, `__getitem__ ->
+  (FloatTensor[n_mels, T], int)` over the reference's Parquet schema `rel_path, fold, class_id, class_name,
+  log_mel_flat, log_mel_shape` (spectrogram.py:166-173,184-212).
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional
+
+import numpy as np
+import torch
+from torch.utils.data import Dataset
+
+from . import _lib
+
+SAMPLE_RATE = int(os.getenv("SAMPLE_RATE", 16000))
+N_MELS = int(os.getenv("N_MELS", 128))
+N_FFT = int(os.getenv("N_FFT", 1024))
+HOP_LENGTH = int(os.getenv("HOP_LENGTH", 512))
+FMIN = int(os.getenv("FMIN", 0))
+FMAX = int(os.getenv("FMAX", 8000))
+DURATION = float(os.getenv("DURATION", 4.0))
+PROCESSED_PARQUET_PATH = os.getenv("PROCESSED_PARQUET_PATH", "./.data/UrbanSound8K/processed")
+
+
+def get_processed_parquet_filename(n_mels: int = None, hop: int = None) -> str:
+    """spectrogram.py:94-96."""
+    return f"urbansound8k_processed_mels{n_mels or N_MELS}_hop{hop or HOP_LENGTH}.parquet"
+
+
+def get_processed_parquet_path() -> str:
+    return os.path.join(PROCESSED_PARQUET_PATH, get_processed_parquet_filename())
+
+
+def prepare_waveform(waveform: torch.Tensor, sample_rate: int = SAMPLE_RATE, duration: float = DURATION) -> torch.Tensor:
+    """[C, n] or [n] -> [1, int(sr * duration)]: channel mean, zero-pad or truncate (spectrogram.py:145-157)."""
+    w = waveform.float()
+    if w.dim() == 1:
+        w = w.unsqueeze(0)
+    if w.shape[0] > 1:
+        w = torch.mean(w, dim=0, keepdim=True)
+    n = int(sample_rate * duration)
+    if w.shape[1] < n:
+        w = torch.nn.functional.pad(w, (0, n - w.shape[1]))
+    else:
+        w = w[:, :n]
+    return w
+
+
+def mel_spectrogram_log(waveform: torch.Tensor, sample_rate: int = None, n_fft: int = None, hop_length: int = None,
+                        n_mels: int = None, f_min: float = None, f_max: float = None, log_eps: float = 1e-6) -> torch.Tensor:
+    """Device waveform [B, n] (or [n]) fp32 -> device [B, n_mels, 1 + n // hop] = ln(mel_power + 1e-6)."""
+    sample_rate = sample_rate or SAMPLE_RATE
+    n_fft, hop_length, n_mels = n_fft or N_FFT, hop_length or HOP_LENGTH, n_mels or N_MELS
+    f_min = FMIN if f_min is None else f_min
+    f_max = FMAX if f_max is None else f_max
+    w = waveform.float()
+    squeeze = w.dim() == 1
+    if squeeze:
+        w = w.unsqueeze(0)
+    if not w.is_cuda:
+        w = w.cuda()
+    w = w.contiguous()
+    B, n = w.shape
+    out = torch.empty((B, n_mels, 1 + n // hop_length), dtype=torch.float32, device=w.device)
+    with torch.cuda.device(w.device):
+        _lib.check(_lib.lib().awt_logmel_generic(_lib.ctx(w.device), _lib.ptr(w), w.stride(0), B, n, sample_rate, n_fft, hop_length,
+                                                 n_mels, float(f_min), float(f_max), float(log_eps), _lib.ptr(out),
+                                                 _lib.stream_handle()))
+    return out[0] if squeeze else out
+
+
+def record_for_parquet(rel_path: str, fold: int, class_id: int, class_name: str, log_mel: torch.Tensor) -> dict:
+    """One row of the reference's Parquet schema (spectrogram.py:165-173)."""
+    a = log_mel.detach().cpu().numpy().astype(np.float32)
+    return {"rel_path": rel_path, "fold": fold, "class_id": class_id, "class_name": class_name,
+            "log_mel_flat": a.flatten(), "log_mel_shape": list(a.shape)}
+
+
+class UrbanSoundDataSet(Dataset):
+    def __init__(self, parquet_path: Optional[str] = None, folds=None):
+        import pandas as pd
+
+        if parquet_path is None:
+            parquet_path = get_processed_parquet_path()
+        self.df = pd.read_parquet(parquet_path)
+        if folds is not None:
+            self.df = self.df[self.df["fold"].isin(folds)].reset_index(drop=True)
+        self.n_mels = N_MELS
+
+    def __len__(self):
+        return len(self.df)
+
+    def __getitem__(self, idx):
+        row = self.df.iloc[idx]
+        log_mel = np.array(row["log_mel_flat"], dtype=np.float32).reshape(tuple(row["log_mel_shape"]))
+        return torch.tensor(log_mel), int(row["class_id"])

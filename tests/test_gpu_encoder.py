@@ -1,0 +1,132 @@
+"""GPU parity of the native encoder (through the C-ABI) vs the fp32 oracle and the committed reference vectors."""
+import numpy as np
+import pytest
+import torch
+
+from mlx8_ws_audio_transformer_amd import weights as wts
+from oracle import encoder as oracle_enc
+from oracle import logmel as oracle_mel
+from tests.util import golden, piano_clips_f32
+
+pytestmark = pytest.mark.gpu
+
+# North-star bound on encoder hidden states: 1e-3.  It is applied as MAX-ABS (the strictest of the three norms
+# SURVEY.md §0.5 lists) to the split-bf16 mode; the single-pass bf16 mode cannot meet it (DESIGN.md "Numerics")
+# and is held to the measured envelope instead.
+PARITY_TOL = 1e-3
+FAST_TOL = {"max_abs": 8e-2, "rel_l2": 1.2e-2}
+
+
+def _mel(cfg, batch, first=0):
+    return oracle_mel.whisper_logmel(piano_clips_f32(batch, first), n_samples=2 * cfg.max_source_positions * 160)
+
+
+def _native(cfg, precision, profile="test", lora=None, chunk=0):
+    from mlx8_ws_audio_transformer_amd.encoder import NativeWhisperEncoder
+    return NativeWhisperEncoder(cfg, precision=precision, lora=lora, seed=0, init_profile=profile, chunk_clips=chunk).eval()
+
+
+@pytest.mark.parametrize("name,trimmed,batch", [("mini", True, 2), ("mini", False, 1), ("tiny", True, 2), ("tiny", False, 2),
+                                                ("small", True, 2), ("small", False, 2)])
+def test_encoder_parity_mode_vs_oracle_and_golden(name, trimmed, batch):
+    cfg = wts.config(name, trimmed)
+    W = wts.init_encoder_weights(cfg, 0, "test")
+    mel = _mel(cfg, batch)
+    enc = _native(cfg, "bf16x3")
+    out = enc(torch.from_numpy(mel).cuda()).last_hidden_state.cpu().numpy()
+    ref = oracle_enc.encoder_forward(W, mel, cfg.heads).numpy()
+    e = oracle_enc.error_norms(out, ref)
+    assert e["max_abs"] < PARITY_TOL, e
+    G = golden("encoder.npz")
+    key = cfg.name
+    np.testing.assert_allclose(out[:, :4], G[f"{key}/last_head"], rtol=0, atol=PARITY_TOL)
+    np.testing.assert_allclose(out[:, -4:], G[f"{key}/last_tail"], rtol=0, atol=PARITY_TOL)
+    if f"{key}/last_full" in G:
+        np.testing.assert_allclose(out, G[f"{key}/last_full"], rtol=0, atol=PARITY_TOL)
+
+
+@pytest.mark.parametrize("name,trimmed", [("tiny", True), ("small", True), ("small", False)])
+def test_encoder_fast_bf16_mode_envelope(name, trimmed):
+    cfg = wts.config(name, trimmed)
+    W = wts.init_encoder_weights(cfg, 0, "hf")
+    mel = _mel(cfg, 1)
+    out = _native(cfg, "bf16", "hf")(torch.from_numpy(mel).cuda()).last_hidden_state.cpu().numpy()
+    e = oracle_enc.error_norms(out, oracle_enc.encoder_forward(W, mel, cfg.heads).numpy())
+    assert e["max_abs"] < FAST_TOL["max_abs"] and e["rel_l2"] < FAST_TOL["rel_l2"], e
+
+
+def test_chunking_is_invisible():
+    cfg = wts.config("tiny", True)
+    mel = torch.from_numpy(_mel(cfg, 5)).cuda()
+    a = _native(cfg, "bf16x3", chunk=2)(mel).last_hidden_state
+    b = _native(cfg, "bf16x3", chunk=16)(mel).last_hidden_state
+    assert torch.equal(a, b)
+
+
+def test_wrong_mel_length_raises_like_reference():
+    cfg = wts.config("mini")
+    enc = _native(cfg, "bf16x3")
+    with pytest.raises(ValueError, match="length 3000"):
+        enc(torch.zeros(1, 80, 400).cuda())
+    enc(torch.zeros(1, 80, 3000).cuda(), attention_mask=torch.ones(1, 3000))  # accepted and ignored
+
+
+def test_module_surface_and_state_dict_roundtrip():
+    cfg = wts.config("mini", True)
+    enc = _native(cfg, "bf16x3")
+    assert enc.config.d_model == 128 and enc.device.type == "cuda"
+    keys = set(enc.state_dict().keys())
+    assert keys == {n for n, _ in wts.encoder_param_shapes(cfg)}
+    W2 = wts.init_encoder_weights(cfg, 7, "test")
+    enc.load_state_dict({k: torch.from_numpy(v) for k, v in W2.items()})
+    mel = _mel(cfg, 1)
+    out = enc(torch.from_numpy(mel).cuda()).last_hidden_state.cpu().numpy()
+    ref = oracle_enc.encoder_forward(W2, mel, cfg.heads).numpy()
+    assert np.abs(out - ref).max() < PARITY_TOL
+
+
+@pytest.mark.parametrize("targets,r", [(("q_proj", "v_proj"), 8), (("q_proj", "k_proj", "v_proj", "out_proj", "fc1", "fc2"), 16)])
+def test_lora_forward(targets, r):
+    cfg = wts.config("tiny", True)
+    spec = wts.LoraSpec(r=r, alpha=16.0, targets=targets)
+    W = wts.init_encoder_weights(cfg, 0, "test")
+    LW = wts.init_lora_weights(cfg, spec, 0, zero_b=False)
+    enc = _native(cfg, "bf16x3", lora=spec)
+    sd = {k: torch.from_numpy(v) for k, v in {**W, **LW}.items()}
+    enc.load_state_dict(sd)
+    mel = _mel(cfg, 2)
+    out = enc(torch.from_numpy(mel).cuda()).last_hidden_state.cpu().numpy()
+    ref = oracle_enc.encoder_forward({**W, **LW}, mel, cfg.heads, lora_scale=spec.scale).numpy()
+    base = oracle_enc.encoder_forward(W, mel, cfg.heads).numpy()
+    assert np.abs(ref - base).max() > 1e-2          # the adapters matter
+    assert np.abs(out - ref).max() < PARITY_TOL
+
+
+def test_pcm_to_hidden_states_end_to_end():
+    from mlx8_ws_audio_transformer_amd import synth
+    cfg = wts.config("tiny")
+    W = wts.init_encoder_weights(cfg, 0, "test")
+    pcm = synth.synth_clips_i16(3, seed=1234, first=20)
+    enc = _native(cfg, "bf16x3", chunk=2)
+    hidden, feats = enc.encode_pcm(torch.from_numpy(pcm).cuda(), return_features=True)
+    mel = oracle_mel.whisper_logmel([synth.pcm_i16_to_f32(c) for c in pcm])
+    np.testing.assert_allclose(feats.cpu().numpy(), mel, rtol=0, atol=1e-5)
+    ref = oracle_enc.encoder_forward(W, mel, cfg.heads).numpy()
+    assert np.abs(hidden.cpu().numpy() - ref).max() < PARITY_TOL
+
+
+def test_whisper_audio_encoder_matches_per_sample_reference_semantics():
+    from mlx8_ws_audio_transformer_amd.audio_encoder import WhisperAudioEncoder
+    cfg = wts.config("mini")
+    W = wts.init_encoder_weights(cfg, 0, "test")
+    clips = piano_clips_f32(2, first=30)
+    ragged = [clips[0][:40000], np.stack([clips[1], clips[1] * 0.5])]     # second one "stereo" [2, n]
+    tower = WhisperAudioEncoder(cfg, state_dict={k: torch.from_numpy(v) for k, v in W.items()})
+    out = tower(ragged, 16000).cpu().numpy()
+    # reference semantics: mono mean, zero-pad to the batch max, then per-sample processor + encoder
+    mono = [ragged[0], ragged[1].mean(axis=0)]
+    mel = oracle_mel.whisper_logmel(mono)
+    ref = oracle_enc.encoder_forward(W, mel, cfg.heads).numpy()
+    assert out.shape == (2, 1500, 128) and np.abs(out - ref).max() < PARITY_TOL
+    with pytest.raises(ValueError, match="16000"):
+        tower(ragged, 8000)

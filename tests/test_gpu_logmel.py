@@ -1,0 +1,93 @@
+"""GPU parity: HIP log-mel kernels (through the C-ABI) vs the oracle and the committed reference vectors."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import logmel as oracle
+from tests.util import golden, logmel_inputs, piano_clips_f32
+
+pytestmark = pytest.mark.gpu
+
+MEL_TOL = 1e-5  # north-star tolerance for mel bins (fp32)
+
+
+@pytest.fixture(scope="module")
+def fe():
+    from mlx8_ws_audio_transformer_amd.feature_extraction import WhisperFeatureExtractor
+    return WhisperFeatureExtractor()
+
+
+@pytest.mark.parametrize("name", ["noise", "tone", "zeros", "short", "piano"])
+def test_whisper_logmel_matches_golden_and_oracle(fe, name):
+    G = golden("logmel_whisper.npz")
+    clip = logmel_inputs()[name]
+    out = fe(clip, sampling_rate=16000, return_tensors="np")["input_features"]
+    assert out.shape == (1, 80, 3000) and out.dtype == np.float32
+    np.testing.assert_allclose(out[0, :, :404], G[f"{name}_np_live"], rtol=0, atol=MEL_TOL)
+    np.testing.assert_allclose(out[0], oracle.whisper_logmel([clip])[0], rtol=0, atol=MEL_TOL)
+
+
+def test_batch_ragged_lengths_and_per_clip_max(fe):
+    ins = logmel_inputs()
+    clips = [ins["tone"], ins["short"] * 0.01, ins["piano"][:12345], np.zeros(7, np.float32), ins["noise"]]
+    out = fe(clips, sampling_rate=16000, return_tensors="pt")["input_features"]
+    assert out.device.type == "cpu" and tuple(out.shape) == (5, 80, 3000)
+    np.testing.assert_allclose(out.numpy(), oracle.whisper_logmel(clips), rtol=0, atol=MEL_TOL)
+
+
+def test_int16_pcm_path_and_device_entry_point():
+    from mlx8_ws_audio_transformer_amd import synth
+    from mlx8_ws_audio_transformer_amd.feature_extraction import logmel_whisper_device
+    pcm = synth.synth_clips_i16(6, seed=1234, first=10)
+    dev = torch.from_numpy(pcm).cuda()
+    out = logmel_whisper_device(dev).cpu().numpy()
+    ref = oracle.whisper_logmel([synth.pcm_i16_to_f32(c) for c in pcm])
+    np.testing.assert_allclose(out, ref, rtol=0, atol=MEL_TOL)
+
+
+def test_full_30s_clip_and_truncation(fe):
+    x = np.concatenate([logmel_inputs()["tone"]] * 8)[:500000]   # longer than 30 s: truncated like the reference
+    out = fe(x, sampling_rate=16000, return_tensors="np")["input_features"][0]
+    np.testing.assert_allclose(out, oracle.whisper_logmel([x])[0], rtol=0, atol=MEL_TOL)
+
+
+def test_trimmed_mode(fe):
+    G = golden("logmel_whisper.npz")
+    out = fe(logmel_inputs()["tone"], sampling_rate=16000, return_tensors="np", max_length=64000)["input_features"][0]
+    assert out.shape == (80, 400)
+    np.testing.assert_allclose(out, G["tone_torch_trimmed"], rtol=0, atol=MEL_TOL)
+    np.testing.assert_allclose(out, oracle.whisper_logmel([logmel_inputs()["tone"]], n_samples=64000)[0], rtol=0, atol=MEL_TOL)
+
+
+def test_reference_error_behaviour(fe):
+    with pytest.raises(ValueError, match="16000"):
+        fe(np.zeros(100, np.float32), sampling_rate=8000)
+    with pytest.raises(ValueError, match="mono"):
+        fe(np.zeros((2, 2, 100), np.float32), sampling_rate=16000)
+    m = fe(logmel_inputs()["short"], sampling_rate=16000, return_tensors="np", return_attention_mask=True)["attention_mask"]
+    assert m.shape == (1, 3000) and m[0, :100].all() and m.sum() == 100
+
+
+@pytest.mark.parametrize("n_mels,hop", [(80, 512), (128, 512), (128, 128), (64, 512)])
+def test_urbansound_logmel(n_mels, hop):
+    from mlx8_ws_audio_transformer_amd import urbansound
+    G3 = golden("logmel_urbansound.npz")
+    tone = logmel_inputs()["tone"]
+    out = urbansound.mel_spectrogram_log(torch.from_numpy(tone), n_fft=1024, hop_length=hop, n_mels=n_mels).cpu().numpy()
+    ref = oracle.urbansound_logmel(tone, n_fft=1024, hop=hop, n_mels=n_mels)
+    assert out.shape == ref.shape
+    np.testing.assert_allclose(out, ref, rtol=0, atol=MEL_TOL)
+    np.testing.assert_allclose(out, G3[f"mels{n_mels}_hop{hop}"], rtol=0, atol=2e-4)  # fp32 torch.stft restatement
+
+
+def test_urbansound_batch_and_prepare():
+    from mlx8_ws_audio_transformer_amd import urbansound
+    clips = piano_clips_f32(3)
+    st = torch.from_numpy(np.stack([clips[0][:30000], clips[1][:30000]]))       # "stereo", short
+    w = urbansound.prepare_waveform(st)
+    assert tuple(w.shape) == (1, 64000)
+    np.testing.assert_array_equal(w[0].numpy(), oracle.urbansound_prepare(st.numpy()))
+    batch = torch.from_numpy(np.stack(clips))
+    out = urbansound.mel_spectrogram_log(batch, n_mels=80).cpu().numpy()
+    for i in range(3):
+        np.testing.assert_allclose(out[i], oracle.urbansound_logmel(clips[i], n_mels=80), rtol=0, atol=MEL_TOL)

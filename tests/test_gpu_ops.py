@@ -1,0 +1,69 @@
+"""GPU parity of the individual HIP kernels (through the C-ABI) against plain PyTorch fp32 on the same inputs."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).cuda()
+
+
+# tolerances: split-bf16 products carry ~2^-16 relative operand error, single bf16 ~2^-8
+TOL = {"bf16x3": 2e-5, "bf16": 1.5e-2}
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 256, 192), (1500, 384, 768), (77, 128, 3072)])
+def test_linear(precision, M, N, K):
+    from mlx8_ws_audio_transformer_amd import ops
+    x, w, b = _rand((M, K), 1), _rand((N, K), 2, K ** -0.5), _rand((N,), 3)
+    y = ops.linear(x, w, b, precision)
+    ref = torch.nn.functional.linear(x.double(), w.double(), b.double())
+    err = (y.double() - ref).abs().max().item()
+    assert err < TOL[precision] * max(1.0, ref.abs().max().item()), err
+
+
+def test_linear_identity_with_asymmetric_weight():
+    # A = I, asymmetric W: catches a transposed C write (cdna_hip_programming.md §3)
+    from mlx8_ws_audio_transformer_amd import ops
+    x = torch.eye(128).cuda()
+    w = (torch.arange(128 * 128, dtype=torch.float32).reshape(128, 128) % 251 - 125).cuda() / 64
+    y = ops.linear(x, w, None, "bf16x3")
+    assert torch.equal(y, w.t().contiguous())
+
+
+@pytest.mark.parametrize("d", [128, 384, 512, 768])
+def test_layernorm(d):
+    from mlx8_ws_audio_transformer_amd import ops
+    x, g, b = _rand((777, d), 4, 3.0) + 1.5, _rand((d,), 5) + 1.0, _rand((d,), 6)
+    y = ops.layernorm(x, g, b)
+    ref = torch.nn.functional.layer_norm(x, (d,), g, b, 1e-5)
+    assert (y - ref).abs().max().item() < 5e-6
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("B,H,S", [(1, 2, 64), (2, 3, 200), (1, 2, 1500), (1, 1, 129)])
+def test_attention(precision, B, H, S):
+    from mlx8_ws_audio_transformer_amd import ops
+    q, k, v = _rand((B, H, S, 64), 7, 0.35), _rand((B, H, S, 64), 8), _rand((B, H, S, 64), 9)
+    o = ops.attention(q, k, v, precision)
+    p = torch.softmax(q.double() @ k.double().transpose(2, 3), dim=-1)
+    ref = (p @ v.double()).transpose(1, 2).reshape(B, S, H * 64)
+    err = (o.double() - ref).abs().max().item()
+    assert err < (1e-4 if precision == "bf16x3" else 2e-2), err  # v_exp_f32 is ~1 ulp; |o| <= ~4
+
+
+def test_attention_online_softmax_rescale_branch():
+    # one key per late tile dominates one query's row: forces the running maximum to jump tile after tile
+    from mlx8_ws_audio_transformer_amd import ops
+    B, H, S = 1, 1, 448
+    q, k, v = _rand((B, H, S, 64), 10, 0.2), _rand((B, H, S, 64), 11), _rand((B, H, S, 64), 12)
+    for t, key in enumerate([70, 150, 260, 390]):
+        k[0, 0, key] = q[0, 0, 5] * (20.0 + 15 * t)
+    o = ops.attention(q, k, v, "bf16x3")
+    p = torch.softmax(q.double() @ k.double().transpose(2, 3), dim=-1)
+    ref = (p @ v.double()).transpose(1, 2).reshape(B, S, 64)
+    assert (o.double() - ref).abs().max().item() < 1e-4
