@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""Throughput of the hot path: 4 s @ 16 kHz clips/sec through log-mel + Whisper-small encoder on N MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one pass of the hot path over one batch of synthetic clips per GPU: int16 PCM [B, 64000] already
+resident in HBM -> Whisper log-mel [B, 80, 3000] -> Whisper-small encoder -> last_hidden_state [B, 1500, 768] fp32,
+all inside `awt_audio_encode` (libawt, hand-written HIP).  Reference semantics ("parity mode"): every clip is
+zero-padded to 30 s and all 1500 positions are attended; weights are random-init of the Whisper-small
+architecture (no checkpoint offline).  Clips shard across ranks with no data-path collective (weak scaling).
+
+The JSON line carries, besides the driver's contract fields:
+  roofline      the dominant kernel class (the MFMA GEMMs), timed live with HIP events on the launch stream;
+                achieved = algorithmic FLOP (2 M N K per launch) / event time, peak = dense bf16 MFMA peak
+  cpu_baseline  oracle/ (CPU restatement of the reference) timed on this host's cores on a bounded sample (rank 0, N=1)
+  parity        HIP outputs vs that oracle on the same sample
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_DENSE_TFLOPS = 2500.0   # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
+ENCODER_GFLOP_PER_CLIP = {("small", False): 344.16, ("small", True): 36.30, ("tiny", False): 36.94, ("tiny", True): 3.33,
+                          ("base", False): 87.37}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--model", default="small")
+    ap.add_argument("--batch", type=int, default=64, help="clips per GPU per step")
+    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16"],
+                    help="bf16x3 (default) meets the 1e-3 hidden-state bound; bf16 is the single-pass fast mode")
+    ap.add_argument("--trimmed", action="store_true", help="T=400/S=200 mode (NOT reference-equivalent)")
+    ap.add_argument("--chunk", type=int, default=0, help="clips per kernel wave inside the library (0 = default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fast-mode", action="store_true")
+    ap.add_argument("--cpu-clips", type=int, default=8)
+    return ap.parse_args()
+
+
+def timed_steps(enc, pcm, steps, world, dev):
+    """barrier + synchronize on both sides, returns max-over-ranks seconds for exactly `steps` steps."""
+    import torch.distributed as dist
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    out = None
+    for _ in range(steps):
+        out = enc.encode_pcm(pcm)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, out
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from mlx8_ws_audio_transformer_amd import _lib, synth, weights as wts
+    from mlx8_ws_audio_transformer_amd.encoder import NativeWhisperEncoder
+
+    cfg = wts.config(a.model, a.trimmed)
+    B = a.batch
+    # synthetic clips: this rank's contiguous shard of the seeded piano-note set
+    pcm_host = synth.synth_clips_i16(B, seed=1234, first=rank * B)
+    pcm = torch.from_numpy(pcm_host).to(dev)
+    enc = NativeWhisperEncoder(cfg, precision=a.precision, device=str(dev), chunk_clips=a.chunk, seed=0, init_profile="hf").eval()
+
+    for _ in range(a.warmup):
+        enc.encode_pcm(pcm)
+    torch.cuda.synchronize(dev)
+
+    # ---- timed region (HIP-event timing of the GEMM class is live inside it)
+    _lib.prof_enable(True)
+    for k in _lib.PROF_CLASSES:
+        _lib.prof_collect(k)
+    dt, out = timed_steps(enc, pcm, a.steps, world, dev)
+    prof = {k: _lib.prof_collect(k) for k in _lib.PROF_CLASSES}
+    _lib.prof_enable(False)
+
+    clips = B * world * a.steps
+    value = clips / dt
+    gemm_ms, gemm_n, gemm_flop = prof["gemm"]
+    achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    terms = 3 if a.precision == "bf16x3" else 1
+    result = {
+        "metric": "4s@16kHz clips/sec through mel+Whisper-%s encoder" % a.model,
+        "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "int16 PCM [B,64000] in HBM -> Whisper log-mel [B,80,%d] -> Whisper-%s encoder -> hidden [B,%d,%d] fp32"
+                               % (cfg.n_frames, a.model, cfg.max_source_positions, cfg.d_model),
+                   "mode": "trimmed (NOT reference-equivalent)" if a.trimmed else "parity (clip zero-padded to 30 s, as the reference computes)",
+                   "clips_per_gpu_per_step": B, "precision": a.precision,
+                   "mfma_products_per_fragment_pair": terms, "weights": "random-init Whisper-%s shape, seed 0" % a.model,
+                   "parallelism": "dp%d (clip shards, no data-path collective)" % world},
+        "roofline": {"bound": "mfma", "kernel": "gemm_kernel<TERMS=%d> (all encoder GEMMs: conv stem, QKV, out, fc1, fc2)" % terms,
+                     "achieved": round(achieved, 2), "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(achieved / PEAK_BF16_DENSE_TFLOPS, 4), "traffic": None,
+                     "launches": gemm_n, "avg_launch_ms": round(gemm_ms / max(gemm_n, 1), 4),
+                     "mfma_issue_frac": round(terms * achieved / PEAK_BF16_DENSE_TFLOPS, 4)},
+        "time_share_ms_per_step": {k: round(v[0] / a.steps, 3) for k, v in prof.items()},
+    }
+    gf = ENCODER_GFLOP_PER_CLIP.get((a.model, a.trimmed))
+    if gf:
+        result["end_to_end_algorithmic_tflops"] = round(value * gf / 1e3, 2)
+        result["end_to_end_frac_of_mfma_peak"] = round(value * gf / 1e3 / PEAK_BF16_DENSE_TFLOPS / world, 4)
+
+    if rank == 0 and world == 1:
+        # ---- single-pass bf16 mode, reported beside the headline (it does not meet the 1e-3 bound)
+        if not a.no_fast_mode and a.precision == "bf16x3":
+            fast = NativeWhisperEncoder(cfg, precision="bf16", device=str(dev), chunk_clips=a.chunk, seed=0, init_profile="hf").eval()
+            for _ in range(max(1, a.warmup)):
+                fast.encode_pcm(pcm)
+            fdt, fout = timed_steps(fast, pcm, a.steps, 1, dev)
+            d = (fout[: a.cpu_clips].double() - out[: a.cpu_clips].double())
+            result["fast_bf16_mode"] = {"value": round(B * a.steps / fdt, 2), "unit": "clips/s",
+                                        "ms_per_step": round(fdt / a.steps * 1e3, 3),
+                                        "vs_bf16x3_max_abs": float(d.abs().max()), "vs_bf16x3_rel_l2": float(d.norm() / out[: a.cpu_clips].double().norm()),
+                                        "note": "single bf16 MFMA product per fragment pair; misses the 1e-3 hidden-state bound"}
+            del fast
+        # ---- CPU baseline: the oracle (CPU restatement of the reference path) on this host's cores, bounded sample
+        if not a.no_cpu_baseline:
+            from oracle import encoder as oenc, logmel as omel
+            n = min(a.cpu_clips, B)
+            # the GPU box gives one GPU's share of the host (16 cores); os.cpu_count() reports the whole machine
+            ncpu = min(len(os.sched_getaffinity(0)), int(os.environ.get("AWT_CPU_THREADS", "16")))
+            torch.set_num_threads(ncpu)
+            W = wts.init_encoder_weights(cfg, 0, "hf")
+            clips_f32 = [synth.pcm_i16_to_f32(c) for c in pcm_host[:n]]
+            t0 = time.perf_counter()
+            mel = omel.whisper_logmel(clips_f32, n_samples=cfg.n_frames * 160)
+            t1 = time.perf_counter()
+            with torch.no_grad():
+                ref = oenc.encoder_forward(W, mel, cfg.heads)
+            t2 = time.perf_counter()
+            result["cpu_baseline"] = {"value": round(n / (t2 - t0), 3), "unit": "clips/s", "cores": torch.get_num_threads(),
+                                      "kind": "port", "sample": "%d of the step's clips, fp32, 1 pass (mel %.2f s + encoder %.2f s)" % (n, t1 - t0, t2 - t1),
+                                      "mel_clips_per_s": round(n / (t1 - t0), 3), "encoder_clips_per_s": round(n / (t2 - t1), 3)}
+            hid, feats = enc.encode_pcm(pcm[:n], return_features=True)
+            e = oenc.error_norms(hid.cpu().numpy(), ref.numpy())
+            result["parity"] = {"mel_max_abs": float(np.abs(feats.cpu().numpy() - mel).max()), "mel_tolerance": 1e-5,
+                                "hidden_max_abs": e["max_abs"], "hidden_mean_abs": e["mean_abs"], "hidden_rel_l2": e["rel_l2"],
+                                "hidden_tolerance": 1e-3, "norm_applied": "max_abs", "sample_clips": n}
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -53,7 +53,7 @@ def test_attention(precision, B, H, S):
     p = torch.softmax(q.double() @ k.double().transpose(2, 3), dim=-1)
     ref = (p @ v.double()).transpose(1, 2).reshape(B, S, H * 64)
     err = (o.double() - ref).abs().max().item()
-    assert err < (1e-4 if precision == "bf16x3" else 2e-2), err  # v_exp_f32 is ~1 ulp; |o| <= ~4
+    assert err < (1e-4 if precision == "bf16x3" else 4e-2), err  # v_exp_f32 ~1 ulp; bf16 rounds q, k, v and P
 
 
 def test_attention_online_softmax_rescale_branch():
