@@ -124,3 +124,4 @@ int logmel_whisper_impl(awt_ctx* c, const void* pcm, int pcm_is_i16, int64_t pcm
 int logmel_generic_impl(awt_ctx* c, const float* pcm, int64_t pcm_stride, int B, int n_samples, int sample_rate, int n_fft,
                         int hop, int n_mels, float f_min, float f_max, float log_eps, float* out, hipStream_t s);
 void awt_free_tables(awt_ctx* c);
+void awt_gemm_force_tile(int t);  // 0 auto, 128 or 256: tuning / tests

@@ -8,7 +8,10 @@
 // * K-segments let one kernel serve: plain linears (1 segment), linears with a LoRA term
 //   ([x | u] . [W | B]^T, 2 segments) and the stride-2 conv stem as an implicit GEMM (3 taps = 3 segments whose
 //   source row is 2 s + tap - 1, rows outside the clip reading as zero).
-// * 128 x 128 block tile, 4 waves (2 x 2), each wave 64 x 64 = 4 x 4 tiles of v_mfma_f32_16x16x32_bf16.
+// * two block tiles: 256 x 256 (8 waves as 2 x 4, each 128 x 64 = 8 x 4 tiles of v_mfma_f32_16x16x32_bf16; one
+//   workgroup per CU, 128 KiB LDS) for the large-N encoder shapes -- at 128 x 128 the L2 -> LDS traffic per MFMA
+//   FLOP is twice as high and the kernel sits on the L2 bandwidth instead of the matrix pipe -- and 128 x 128
+//   (4 waves as 2 x 2) for N not a multiple of 256.
 //   Tiles are staged global -> LDS with 16-byte LDS-DMA (global_load_lds_dwordx4), double buffered, one barrier per
 //   K-tile; LDS rows are XOR-swizzled on the SOURCE address (the DMA writes LDS linearly) and on the ds_read_b128,
 //   so fragment reads are bank-conflict free.
@@ -18,7 +21,6 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, kThreads = 256;
 constexpr int kMaxSeg = 3;
 
 struct GemmArgs {
@@ -28,18 +30,26 @@ struct GemmArgs {
   const bf16_t* zeros;   // >= 128 zero bytes (padding rows of the conv stem)
 };
 
+// block-tile configurations: WM x WN waves, each wave TM x TN tiles of 16 x 16
+struct Cfg128 { static constexpr int WM = 2, WN = 2, TM = 4, TN = 4; };
+struct Cfg256 { static constexpr int WM = 2, WN = 4, TM = 8, TN = 4; };
+
 template <int BK> __device__ __forceinline__ int swz(int row);
 // BK = 64: 128-byte rows, 8 chunks of 16 B; BK = 32: 64-byte rows, 4 chunks.  See DESIGN.md "LDS images".
 template <> __device__ __forceinline__ int swz<64>(int row) { return (row >> 1) & 7; }
 template <> __device__ __forceinline__ int swz<32>(int row) { return (0x1320 >> (((row >> 2) & 3) * 4)) & 3; }  // {0,2,3,1}
 
-template <int TERMS, int BK>
+template <int TERMS, int BK, class CFG>
 struct Tile {
-  static constexpr int NPL = (TERMS == 3) ? 4 : 2;          // planes per stage: A_hi, (A_lo), W_hi, (W_lo)
-  static constexpr int PLANE = 128 * BK * 2;                // bytes
-  static constexpr int STAGE = NPL * PLANE;
+  static constexpr int BM = CFG::WM * CFG::TM * 16, BN = CFG::WN * CFG::TN * 16;
+  static constexpr int THREADS = CFG::WM * CFG::WN * 64;
+  static constexpr int NP = (TERMS == 3) ? 2 : 1;           // planes per operand: hi (+ lo)
+  static constexpr int PLANE_A = BM * BK * 2, PLANE_W = BN * BK * 2;   // bytes
+  static constexpr int OFF_W = NP * PLANE_A;
+  static constexpr int STAGE = NP * (PLANE_A + PLANE_W);
   static constexpr int CPR = BK / 8;                        // 16-byte chunks per row
-  static constexpr int ITERS = (128 * CPR) / kThreads;      // LDS-DMA instructions per thread per plane
+  static constexpr int ITERS_A = (BM * CPR) / THREADS;      // LDS-DMA instructions per thread per plane
+  static constexpr int ITERS_W = (BN * CPR) / THREADS;
 };
 
 __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
@@ -49,11 +59,11 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
 
 // Per-thread staging state: the rows a thread copies are the same for every K-tile, so the (row-mapped) source
 // pointers are computed once per K-segment and only advanced by BK elements per K-tile.
-template <int TERMS, int BK>
+template <int TERMS, int BK, class CFG>
 struct Stager {
-  using T = Tile<TERMS, BK>;
-  const bf16_t* a_hi[T::ITERS]; const bf16_t* a_lo[T::ITERS];
-  const bf16_t* w_hi[T::ITERS]; const bf16_t* w_lo[T::ITERS];
+  using T = Tile<TERMS, BK, CFG>;
+  const bf16_t* a_hi[T::ITERS_A]; const bf16_t* a_lo[T::ITERS_A];
+  const bf16_t* w_hi[T::ITERS_W]; const bf16_t* w_lo[T::ITERS_W];
   int si, kk, nk;
 
   __device__ __forceinline__ void open_segment(const GemmArgs& g, int seg, int m0, int n0, int wave, int lane) {
@@ -61,8 +71,8 @@ struct Stager {
     const GemmSeg& sg = g.seg[seg];
     nk = sg.K / BK;
 #pragma unroll
-    for (int it = 0; it < T::ITERS; ++it) {
-      const int p = it * kThreads + wave * 64 + lane;           // linear 16-byte slot in the plane
+    for (int it = 0; it < T::ITERS_A; ++it) {
+      const int p = it * T::THREADS + wave * 64 + lane;         // linear 16-byte slot in the plane
       const int row = p / T::CPR;
       const int c = (p % T::CPR) ^ swz<BK>(row);                // source chunk that lands in this slot
       int m = m0 + row; m = m < g.M ? m : g.M - 1;              // M tail: clamp (never stored)
@@ -72,7 +82,14 @@ struct Stager {
       const int64_t aoff = ((int64_t)grp * sg.rows_in + sr) * sg.lda + c * 8;
       a_hi[it] = ok ? sg.a_hi + aoff : nullptr;
       a_lo[it] = (ok && TERMS == 3) ? sg.a_lo + aoff : nullptr;
-      const int64_t woff = (int64_t)(n0 + row) * sg.ldw + c * 8;
+    }
+#pragma unroll
+    for (int it = 0; it < T::ITERS_W; ++it) {
+      const int p = it * T::THREADS + wave * 64 + lane;
+      const int row = p / T::CPR;
+      const int c = (p % T::CPR) ^ swz<BK>(row);
+      int n = n0 + row; n = n < g.N ? n : g.N - 1;
+      const int64_t woff = (int64_t)n * sg.ldw + c * 8;
       w_hi[it] = sg.w_hi + woff;
       w_lo[it] = (TERMS == 3) ? sg.w_lo + woff : nullptr;
     }
@@ -81,12 +98,16 @@ struct Stager {
   __device__ __forceinline__ void stage_and_advance(const GemmArgs& g, char* stage_base, int m0, int n0, int wave, int lane) {
     const int koff = kk * BK;
 #pragma unroll
-    for (int it = 0; it < T::ITERS; ++it) {
-      char* dst = stage_base + (it * kThreads + wave * 64) * 16;
+    for (int it = 0; it < T::ITERS_A; ++it) {
+      char* dst = stage_base + (it * T::THREADS + wave * 64) * 16;
       glds16(a_hi[it] ? (const void*)(a_hi[it] + koff) : (const void*)g.zeros, dst);
-      if (TERMS == 3) glds16(a_lo[it] ? (const void*)(a_lo[it] + koff) : (const void*)g.zeros, dst + T::PLANE);
-      glds16(w_hi[it] + koff, dst + (TERMS == 3 ? 2 : 1) * T::PLANE);
-      if (TERMS == 3) glds16(w_lo[it] + koff, dst + 3 * T::PLANE);
+      if (TERMS == 3) glds16(a_lo[it] ? (const void*)(a_lo[it] + koff) : (const void*)g.zeros, dst + T::PLANE_A);
+    }
+#pragma unroll
+    for (int it = 0; it < T::ITERS_W; ++it) {
+      char* dst = stage_base + T::OFF_W + (it * T::THREADS + wave * 64) * 16;
+      glds16(w_hi[it] + koff, dst);
+      if (TERMS == 3) glds16(w_lo[it] + koff, dst + T::PLANE_W);
     }
     if (++kk == nk && si + 1 < g.nseg) open_segment(g, si + 1, m0, n0, wave, lane);
   }
@@ -120,9 +141,10 @@ __device__ __forceinline__ void store_out(const GemmOut& o, int m, int n, float 
   }
 }
 
-template <int TERMS, int BK, int EPI>
-__global__ __launch_bounds__(kThreads, 2) void gemm_kernel(GemmArgs g) {
-  using T = Tile<TERMS, BK>;
+template <int TERMS, int BK, int EPI, class CFG>
+__global__ __launch_bounds__(CFG::WM * CFG::WN * 64, 2) void gemm_kernel(GemmArgs g) {
+  using T = Tile<TERMS, BK, CFG>;
+  constexpr int TM = CFG::TM, TN = CFG::TN;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -133,21 +155,21 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(GemmArgs g) {
   const int q = nwg >> 3, r = nwg & 7;
   const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
+  const int m0 = tm * T::BM, n0 = tn * T::BN;
 
   int ktiles = 0;
   for (int s = 0; s < g.nseg; ++s) ktiles += g.seg[s].K / BK;
 
-  f32x4 acc[4][4];
+  f32x4 acc[TM][TN];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = wave / CFG::WN, wc = wave - wr * CFG::WN;
   const int frow = lane & 15, fq = lane >> 4;
 
-  Stager<TERMS, BK> st;
+  Stager<TERMS, BK, CFG> st;
   st.open_segment(g, 0, m0, n0, wave, lane);
   st.stage_and_advance(g, smem, m0, n0, wave, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -157,36 +179,41 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(GemmArgs g) {
     char* cur = smem + (kt & 1) * T::STAGE;
     if (kt + 1 < ktiles) st.stage_and_advance(g, smem + ((kt + 1) & 1) * T::STAGE, m0, n0, wave, lane);
     const char* a_hi = cur;
-    const char* a_lo = cur + T::PLANE;
-    const char* w_hi = cur + (TERMS == 3 ? 2 : 1) * T::PLANE;
-    const char* w_lo = cur + 3 * T::PLANE;
+    const char* a_lo = cur + T::PLANE_A;
+    const char* w_hi = cur + T::OFF_W;
+    const char* w_lo = cur + T::OFF_W + T::PLANE_W;
 #pragma unroll
     for (int ks = 0; ks < BK / 32; ++ks) {
-      bf16x8 ah[4], bh[4], al[4], bl[4];
+      bf16x8 bh[TN], bl[TN];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int row = wr * 64 + i * 16 + frow;
-        const int off = row * (BK * 2) + (((ks * 4 + fq) ^ swz<BK>(row)) << 4);
-        ah[i] = *reinterpret_cast<const bf16x8*>(a_hi + off);
-        if (TERMS == 3) al[i] = *reinterpret_cast<const bf16x8*>(a_lo + off);
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int row = wc * 64 + j * 16 + frow;
+      for (int j = 0; j < TN; ++j) {
+        const int row = (wc * TN + j) * 16 + frow;
         const int off = row * (BK * 2) + (((ks * 4 + fq) ^ swz<BK>(row)) << 4);
         bh[j] = *reinterpret_cast<const bf16x8*>(w_hi + off);
         if (TERMS == 3) bl[j] = *reinterpret_cast<const bf16x8*>(w_lo + off);
       }
+      // A fragments four tiles at a time: keeps (TM x TN accumulators + B + 4 A) inside the 256-register budget
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i0 = 0; i0 < TM; i0 += 4) {
+        bf16x8 ah[4], al[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (TERMS == 3) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-          }
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < 4; ++i) {
+          const int row = (wr * TM + i0 + i) * 16 + frow;
+          const int off = row * (BK * 2) + (((ks * 4 + fq) ^ swz<BK>(row)) << 4);
+          ah[i] = *reinterpret_cast<const bf16x8*>(a_hi + off);
+          if (TERMS == 3) al[i] = *reinterpret_cast<const bf16x8*>(a_lo + off);
         }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            if (TERMS == 3) {
+              acc[i0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i0 + i][j], 0, 0, 0);
+              acc[i0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i0 + i][j], 0, 0, 0);
+            }
+            acc[i0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i0 + i][j], 0, 0, 0);
+          }
+      }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -194,42 +221,50 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(GemmArgs g) {
 
   // epilogue: C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
-        const int m = m0 + wr * 64 + i * 16 + fq * 4 + rr;
-        const int n = n0 + wc * 64 + j * 16 + frow;
+        const int m = m0 + (wr * TM + i) * 16 + fq * 4 + rr;
+        const int n = n0 + (wc * TN + j) * 16 + frow;
         store_out<EPI>(g.out, m, n, acc[i][j][rr], g.M);
       }
 }
 
-template <int TERMS, int BK, int EPI>
-int launch_one(const GemmArgs& a, hipStream_t s) {
-  using T = Tile<TERMS, BK>;
+template <int TERMS, int BK, int EPI, class CFG>
+int launch_one(GemmArgs a, hipStream_t s) {
+  using T = Tile<TERMS, BK, CFG>;
   static bool attr = false;
   if (!attr) {
-    AWT_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_kernel<TERMS, BK, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * T::STAGE));
+    AWT_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_kernel<TERMS, BK, EPI, CFG>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * T::STAGE));
     attr = true;
   }
-  hipLaunchKernelGGL((gemm_kernel<TERMS, BK, EPI>), dim3(a.tiles_m * a.tiles_n), dim3(kThreads), 2 * T::STAGE, s, a);
+  a.tiles_m = (a.M + T::BM - 1) / T::BM;
+  a.tiles_n = (a.N + T::BN - 1) / T::BN;
+  hipLaunchKernelGGL((gemm_kernel<TERMS, BK, EPI, CFG>), dim3(a.tiles_m * a.tiles_n), dim3(T::THREADS), 2 * T::STAGE, s, a);
   AWT_HIP_CHECK(hipGetLastError());
   return AWT_OK;
 }
 
+int g_force_tile = 0;  // 0 = auto, 128 / 256 = forced (tuning and tests)
+
 template <int EPI>
 int launch_epi(const GemmArgs& a, int terms, hipStream_t s) {
-  return terms == 3 ? launch_one<3, 32, EPI>(a, s) : launch_one<1, 64, EPI>(a, s);
+  const bool big = g_force_tile ? g_force_tile == 256 : (a.N % 256 == 0 && a.M >= 2048);
+  if (big) return terms == 3 ? launch_one<3, 32, EPI, Cfg256>(a, s) : launch_one<1, 64, EPI, Cfg256>(a, s);
+  return terms == 3 ? launch_one<3, 32, EPI, Cfg128>(a, s) : launch_one<1, 64, EPI, Cfg128>(a, s);
 }
 
 bf16_t* g_zeros = nullptr;
 
 }  // namespace
 
+void awt_gemm_force_tile(int t) { g_force_tile = t; }
+
 int launch_gemm(awt_ctx* c, int M, int N, const GemmSeg* segs, int nseg, int terms, GemmEpilogue epi, const GemmOut& out,
                 hipStream_t s) {
-  AWT_REQUIRE(M > 0 && N > 0 && N % BN == 0, AWT_ERR_INVALID, "gemm: N must be a positive multiple of 128");
+  AWT_REQUIRE(M > 0 && N > 0 && N % 128 == 0, AWT_ERR_INVALID, "gemm: N must be a positive multiple of 128");
   AWT_REQUIRE(nseg >= 1 && nseg <= kMaxSeg, AWT_ERR_INVALID, "gemm: 1..3 K-segments");
   AWT_REQUIRE(terms == 1 || terms == 3, AWT_ERR_INVALID, "gemm: terms must be 1 or 3");
   if (!g_zeros) {
@@ -237,7 +272,7 @@ int launch_gemm(awt_ctx* c, int M, int N, const GemmSeg* segs, int nseg, int ter
     AWT_HIP_CHECK(hipMemset(g_zeros, 0, 256));
   }
   GemmArgs a{};
-  a.M = M; a.N = N; a.nseg = nseg; a.tiles_m = (M + BM - 1) / BM; a.tiles_n = N / BN; a.out = out; a.zeros = g_zeros;
+  a.M = M; a.N = N; a.nseg = nseg; a.out = out; a.zeros = g_zeros;
   double ksum = 0;
   for (int i = 0; i < nseg; ++i) {
     a.seg[i] = segs[i];
