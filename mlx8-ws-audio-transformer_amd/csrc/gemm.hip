@@ -113,31 +113,45 @@ struct Stager {
   }
 };
 
+// Epilogue on four consecutive columns of one row (the accumulators are transposed through LDS first, so a lane owns
+// a 16-byte fp32 / 8-byte bf16 piece of a row and 16 lanes cover 64 contiguous columns).
 template <int EPI>
-__device__ __forceinline__ void store_out(const GemmOut& o, int m, int n, float acc, int M) {
+__device__ __forceinline__ void store_out4(const GemmOut& o, int m, int n, float4 acc, int M) {
   if (m >= M || n >= o.n_valid) return;
-  float v = acc + (o.bias ? o.bias[n] : 0.f);
-  if (EPI == EPI_F32) {
-    o.f32[(int64_t)m * o.ldo + n] = v;
-  } else if (EPI == EPI_F32_RESID) {
-    o.f32[(int64_t)m * o.ldo + n] = o.resid[(int64_t)m * o.ldo + n] + v;
-  } else if (EPI == EPI_F32_GELU_POS) {
-    o.f32[(int64_t)m * o.ldo + n] = gelu_erf(v) + o.pos[(int64_t)(m % o.rows_pos) * o.ldo + n];
-  } else if (EPI == EPI_BF16 || EPI == EPI_BF16_GELU) {
-    v = (EPI == EPI_BF16_GELU) ? gelu_erf(v) : v * o.scale;
-    bf16_t hi, lo; split_bf16(v, hi, lo);
-    o.hi[(int64_t)m * o.ldo + n] = hi;
-    if (o.lo) o.lo[(int64_t)m * o.ldo + n] = lo;
-  } else if (EPI == EPI_QKV) {
-    const int d = o.H * 64;
-    const int which = n / d, within = n - which * d;
-    const int h = within >> 6, e = within & 63;
-    const int b = m / o.S, s = m - b * o.S;
-    if (which == 0) v *= o.scale;
-    bf16_t hi, lo; split_bf16(v, hi, lo);
-    const int64_t off = (int64_t)which * o.plane_stride + (((int64_t)b * o.H + h) * o.S + s) * 64 + e;
-    o.hi[off] = hi;
-    if (o.lo) o.lo[off] = lo;
+  float v[4] = {acc.x, acc.y, acc.z, acc.w};
+  if (o.bias) {
+    const float4 b = *reinterpret_cast<const float4*>(o.bias + n);
+    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+  }
+  if (EPI == EPI_F32 || EPI == EPI_F32_RESID || EPI == EPI_F32_GELU_POS) {
+    float* dst = o.f32 + (int64_t)m * o.ldo + n;
+    if (EPI == EPI_F32_RESID) {
+      const float4 r = *reinterpret_cast<const float4*>(o.resid + (int64_t)m * o.ldo + n);
+      v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+    } else if (EPI == EPI_F32_GELU_POS) {
+      const float4 ps = *reinterpret_cast<const float4*>(o.pos + (int64_t)(m % o.rows_pos) * o.ldo + n);
+      v[0] = gelu_erf(v[0]) + ps.x; v[1] = gelu_erf(v[1]) + ps.y; v[2] = gelu_erf(v[2]) + ps.z; v[3] = gelu_erf(v[3]) + ps.w;
+    }
+    *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+  } else {
+    int64_t off;
+    if (EPI == EPI_QKV) {
+      const int d = o.H * 64;
+      const int which = n / d, within = n - which * d;
+      const int h = within >> 6, e = within & 63;
+      const int b = m / o.S, s = m - b * o.S;
+      if (which == 0) { v[0] *= o.scale; v[1] *= o.scale; v[2] *= o.scale; v[3] *= o.scale; }
+      off = (int64_t)which * o.plane_stride + (((int64_t)b * o.H + h) * o.S + s) * 64 + e;
+    } else {
+      off = (int64_t)m * o.ldo + n;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) v[t] = (EPI == EPI_BF16_GELU) ? gelu_erf(v[t]) : v[t] * o.scale;
+    }
+    bf16_t hi[4], lo[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) split_bf16(v[t], hi[t], lo[t]);
+    *reinterpret_cast<uint2*>(o.hi + off) = make_uint2(pack2(hi[0], hi[1]), pack2(hi[2], hi[3]));
+    if (o.lo) *reinterpret_cast<uint2*>(o.lo + off) = make_uint2(pack2(lo[0], lo[1]), pack2(lo[2], lo[3]));
   }
 }
 
@@ -219,17 +233,29 @@ __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, 2) void gemm_kernel(GemmArg
     __syncthreads();
   }
 
-  // epilogue: C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
+  // epilogue: the C/D layout of the 16x16 MFMA (col = lane & 15, row = (lane >> 4) * 4 + reg) would give 2-4 byte
+  // scattered stores; each wave instead transposes one 16-row x 64-column strip at a time through a private LDS
+  // patch (the staging buffers are dead: the loop's last barrier has passed) and writes whole 256-byte rows.
+  static_assert(TN == 4, "epilogue strips are 64 columns wide");
+  constexpr int PITCH = 68;  // floats; 16 x 68 x 4 B = 4352 B per wave
+  float* patch = reinterpret_cast<float*>(smem) + wave * (16 * PITCH);
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+  for (int i = 0; i < TM; ++i) {
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        const int m = m0 + (wr * TM + i) * 16 + fq * 4 + rr;
-        const int n = n0 + (wc * TN + j) * 16 + frow;
-        store_out<EPI>(g.out, m, n, acc[i][j][rr], g.M);
-      }
+      for (int rr = 0; rr < 4; ++rr) patch[(fq * 4 + rr) * PITCH + j * 16 + frow] = acc[i][j][rr];
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int rl = fq + 4 * it, cl = frow * 4;
+      const float4 v = *reinterpret_cast<const float4*>(patch + rl * PITCH + cl);
+      store_out4<EPI>(g.out, m0 + (wr * TM + i) * 16 + rl, n0 + wc * 64 + cl, v, g.M);
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
 }
 
 template <int TERMS, int BK, int EPI, class CFG>
