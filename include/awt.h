@@ -90,6 +90,8 @@ typedef struct awt_encoder_cfg {
   float lora_alpha;         /* adapter scale = lora_alpha / lora_rank                                      */
   uint32_t lora_targets;    /* bit mask of AWT_LORA_*                                                      */
   int32_t chunk_clips;      /* clips processed per kernel wave (0 = library default)                       */
+  int32_t training;         /* != 0: keep transposed copies of the frozen weights so awt_encoder_backward can run
+                               (adapters on q/k/v only in this mode)                                        */
 } awt_encoder_cfg;
 
 enum { AWT_LORA_Q = 1, AWT_LORA_K = 2, AWT_LORA_V = 4, AWT_LORA_OUT = 8, AWT_LORA_FC1 = 16, AWT_LORA_FC2 = 32 };
@@ -112,6 +114,22 @@ size_t awt_encoder_workspace_bytes(const awt_encoder* e, int B);
  * modeling_whisper.py:612-616). */
 int awt_encoder_forward(awt_encoder* e, const float* input_features, int B, int n_frames, float* last_hidden_state,
                         void* workspace, size_t ws_bytes, void* stream);
+
+/* ---- LoRA fine-tune step (K13/K14; build-defined adapters): the encoder half of
+ * `trainer.train()` (/root/reference/AB/fineTune.py:186-199), with the frozen base weights and trainable A/B.
+ * awt_encoder_forward_train is awt_encoder_forward for the whole batch at once, keeping every activation the backward
+ * pass needs in `saved` (>= awt_encoder_train_workspace_bytes(e, B) bytes, 256-byte aligned, caller-owned, must stay
+ * untouched until awt_encoder_backward has been enqueued on the same stream).
+ * awt_encoder_backward takes d(loss)/d(last_hidden_state) [B, n_ctx, d_model] and writes the gradients of every
+ * adapter into `lora_grads` (float32, awt_encoder_lora_grad_count(e) elements): for each layer in order, for each
+ * enabled target in the order q, k, v: dA [r, d_model] then dB [d_model, r], row-major.  Gradients of frozen weights
+ * and of the input features are not produced (nothing below the first adapter needs them). */
+size_t awt_encoder_train_workspace_bytes(const awt_encoder* e, int B);
+size_t awt_encoder_lora_grad_count(const awt_encoder* e);
+int awt_encoder_forward_train(awt_encoder* e, const float* input_features, int B, int n_frames, float* last_hidden_state,
+                              void* saved, size_t saved_bytes, void* stream);
+int awt_encoder_backward(awt_encoder* e, const float* d_last_hidden_state, int B, void* saved, size_t saved_bytes,
+                         float* lora_grads, size_t n_grads, void* stream);
 
 /* PCM -> hidden states in one call (log-mel + encoder, chunked so intermediates stay cache-resident):
  * the batched form of `WhisperAudioEncoder.forward` (.charles/music2midi/model.py:42-123).

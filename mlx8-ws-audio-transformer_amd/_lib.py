@@ -28,7 +28,7 @@ class AwtError(RuntimeError):
 class EncoderCfg(C.Structure):
     _fields_ = [("d_model", C.c_int32), ("n_layers", C.c_int32), ("n_heads", C.c_int32), ("ffn_dim", C.c_int32),
                 ("n_mels", C.c_int32), ("n_ctx", C.c_int32), ("mfma_terms", C.c_int32), ("lora_rank", C.c_int32),
-                ("lora_alpha", C.c_float), ("lora_targets", C.c_uint32), ("chunk_clips", C.c_int32)]
+                ("lora_alpha", C.c_float), ("lora_targets", C.c_uint32), ("chunk_clips", C.c_int32), ("training", C.c_int32)]
 
 
 LORA_BITS = {"q_proj": 1, "k_proj": 2, "v_proj": 4, "out_proj": 8, "fc1": 16, "fc2": 32}
@@ -48,6 +48,10 @@ _SIGNATURES = {
     "awt_encoder_set_weight": (_i, [_vp, C.c_char_p, _vp, C.POINTER(_i64), _i, _vp]),
     "awt_encoder_workspace_bytes": (_sz, [_vp, _i]),
     "awt_encoder_forward": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
+    "awt_encoder_train_workspace_bytes": (_sz, [_vp, _i]),
+    "awt_encoder_lora_grad_count": (_sz, [_vp]),
+    "awt_encoder_forward_train": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
+    "awt_encoder_backward": (_i, [_vp, _vp, _i, _vp, _sz, _vp, _sz, _vp]),
     "awt_audio_encode_workspace_bytes": (_sz, [_vp, _i]),
     "awt_audio_encode": (_i, [_vp, _vp, _i, _i64, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "awt_op_linear": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),

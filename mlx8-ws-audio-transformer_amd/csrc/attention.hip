@@ -28,6 +28,7 @@ constexpr float kLog2e = 1.4426950408889634f;
 struct AttnArgs {
   const bf16_t *q_hi, *q_lo, *k_hi, *k_lo, *v_hi, *v_lo;
   bf16_t *o_hi, *o_lo; float* o_f32;
+  float* lse;   // optional [B, H, S]: log2-domain log-sum-exp of each score row (saved for the backward pass)
   int B, H, S;
 };
 
@@ -198,6 +199,7 @@ __global__ __launch_bounds__(kThreads, 2) void attention_kernel(AttnArgs a) {
   const float l_tot = l_run + __shfl_xor(l_run, 32);
   const float inv = 1.0f / l_tot;
   const int q = q0 + ql;
+  if (a.lse && q < a.S && half == 0) a.lse[(int64_t)bh * a.S + q] = m_run + __builtin_amdgcn_logf(l_tot);
   if (q < a.S) {
     const int64_t row = ((int64_t)b * a.S + q) * (a.H * 64) + h * 64;
 #pragma unroll
@@ -238,14 +240,14 @@ int launch_t(const AttnArgs& a, hipStream_t s) {
 }  // namespace
 
 int launch_attention(awt_ctx* c, const bf16_t* q_hi, const bf16_t* q_lo, const bf16_t* k_hi, const bf16_t* k_lo,
-                     const bf16_t* v_hi, const bf16_t* v_lo, bf16_t* o_hi, bf16_t* o_lo, float* o_f32, int B, int H,
+                     const bf16_t* v_hi, const bf16_t* v_lo, bf16_t* o_hi, bf16_t* o_lo, float* o_f32, float* lse, int B, int H,
                      int S, int terms, hipStream_t s) {
   AWT_REQUIRE(B > 0 && H > 0 && S > 0, AWT_ERR_INVALID, "attention: bad shape");
   AWT_REQUIRE(terms == 1 || terms == 3, AWT_ERR_INVALID, "attention: terms must be 1 or 3");
   AWT_REQUIRE(q_hi && k_hi && v_hi && (o_hi || o_f32), AWT_ERR_INVALID, "attention: null plane");
   AWT_REQUIRE(terms == 1 || (q_lo && k_lo && v_lo), AWT_ERR_INVALID, "attention: lo planes required for terms == 3");
   AWT_REQUIRE((int64_t)B * H <= 65535, AWT_ERR_INVALID, "attention: B * H exceeds the grid's y extent");
-  AttnArgs a{q_hi, q_lo, k_hi, k_lo, v_hi, v_lo, o_hi, o_lo, o_f32, B, H, S};
+  AttnArgs a{q_hi, q_lo, k_hi, k_lo, v_hi, v_lo, o_hi, o_lo, o_f32, lse, B, H, S};
   ProfScope prof(c, AWT_PROF_ATTENTION, s, 4.0 * (double)B * H * (double)S * S * 64);
   return terms == 3 ? launch_t<3>(a, s) : launch_t<1>(a, s);
 }

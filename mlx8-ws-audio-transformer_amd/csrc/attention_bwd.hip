@@ -1,0 +1,300 @@
+// Flash-style attention backward (part of K14) for head_dim 64, no mask -- gfx950.
+//
+// Given q (pre-scaled), k, v, the forward's log-sum-exp (log2 domain), dO and delta = rowsum(dO * O):
+//   P = exp2(s log2e - lse2),   dV = P^T dO,   dP = dO V^T,   dS = P (dP - delta),   dQ = dS K,   dK = dS^T Q.
+// P is recomputed from the saved row statistics instead of storing the S x S scores.
+//
+// Two launches of one kernel template, neither needs a cross-workgroup sum (deterministic, no atomics):
+//   MODE_DQ   lanes = queries (32 per wave), K and V tiles stream through LDS:   dQ^T += K^T dS^T
+//   MODE_DKV  lanes = keys    (32 per wave), Q and dO tiles stream through LDS:  dK^T += Q^T dS,  dV^T += dO^T P
+// Both follow the forward kernel's shape (attention.hip): the first products are "tile rows x lane-resident
+// fragments" on v_mfma_f32_32x32x16_bf16, their 32x32 accumulators (reduction index in registers, lane index on the
+// lane) become the B operands of the second products, whose A operands are ds_read_b64_tr_b16 transposes of the same
+// LDS tiles (one chunk-XOR-swizzled image serves both the row reads and the transposed reads).
+// TERMS = 3: every operand is a hi + lo bf16 pair, three MFMAs per fragment pair (DESIGN.md "Numerics").
+// Gradients are written as bf16 hi/lo planes in ROW-MAJOR [B*S, 3*d] (dq | dk | dv, dq already multiplied by the
+// head_dim^-1/2 the forward applied to q), which is the K-contiguous A operand of the QKV backward GEMM.
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int LW = 32;            // lane-resident rows per wave
+constexpr int LB = 128;           // ... per workgroup
+constexpr int TB = 64;            // streamed rows per tile
+constexpr int PLANE = TB * 64 * 2;
+constexpr float kLog2e = 1.4426950408889634f;
+
+enum { MODE_DQ = 0, MODE_DKV = 1 };
+
+struct BwdArgs {
+  const bf16_t *q_hi, *q_lo, *k_hi, *k_lo, *v_hi, *v_lo;   // head-major [B, H, S, 64]
+  const bf16_t *do_hi, *do_lo;                              // row-major [B*S, H*64]
+  const float* lse2;                                        // [B, H, S]
+  const float* delta;                                       // [B, H, S]
+  bf16_t *g_hi, *g_lo;                                      // row-major [B*S, 3*H*64]: dq | dk | dv
+  int B, H, S; float qscale;
+};
+
+__device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
+__device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ bf16x4 tr_read(const char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)p);
+}
+
+struct TileSrc { const bf16_t *hi, *lo; int64_t base; int64_t row_stride; };   // element offsets
+
+// stage two 64-row tiles (T1, T2), hi (+ lo) planes, chunk-swizzled; rows beyond S are clamped (masked later)
+template <int TERMS>
+__device__ __forceinline__ void stage_tiles(const TileSrc& t1, const TileSrc& t2, int S, int tt, char* stage, int wave, int lane) {
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int p = it * kThreads + wave * 64 + lane;
+    const int row = p >> 3;
+    const int c = (p & 7) ^ swz(row);
+    int r = tt * TB + row; r = r < S ? r : S - 1;
+    char* dst = stage + (it * kThreads + wave * 64) * 16;
+    const int64_t o1 = t1.base + (int64_t)r * t1.row_stride + c * 8;
+    const int64_t o2 = t2.base + (int64_t)r * t2.row_stride + c * 8;
+    glds16(t1.hi + o1, dst);
+    if (TERMS == 3) glds16(t1.lo + o1, dst + PLANE);
+    glds16(t2.hi + o2, dst + (TERMS == 3 ? 2 : 1) * PLANE);
+    if (TERMS == 3) glds16(t2.lo + o2, dst + 3 * PLANE);
+  }
+}
+
+// acc (32 x 32, rows = tile rows in registers, cols = lanes) += T[rows] . L^T   with L fragments lane-resident
+template <int TERMS>
+__device__ __forceinline__ void rows_times_lane(f32x16& acc, const char* t_hi, const char* t_lo, int row, int half,
+                                                const bf16x8 (&lh)[4], const bf16x8 (&ll)[4]) {
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const int off = row * 128 + (((2 * ks + half) ^ swz(row)) << 4);
+    const bf16x8 th = *reinterpret_cast<const bf16x8*>(t_hi + off);
+    if (TERMS == 3) {
+      const bf16x8 tl = *reinterpret_cast<const bf16x8*>(t_lo + off);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(th, ll[ks], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tl, lh[ks], acc, 0, 0, 0);
+    }
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(th, lh[ks], acc, 0, 0, 0);
+  }
+}
+
+// out^T (64 dims x 32 lanes, two 32-dim tiles) += T^T (transposed read of a 32-row sub-tile) . X, where X is a 32 x 32
+// accumulator tile whose registers 8 s .. 8 s + 7 form the B fragment of k-step s (cdna_hip_programming.md §3)
+template <int TERMS>
+__device__ __forceinline__ void trT_times_acc(f32x16 (&out)[2], const char* t_hi, const char* t_lo, int sub, const f32x16& x, int lane) {
+  const int g = lane >> 4, i = lane & 15, qq = i >> 2, pp = i & 3;
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    bf16x8 xh, xl;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      bf16_t hi, lo;
+      split_bf16(x[8 * s + j], hi, lo);
+      xh[j] = (short)hi;
+      if (TERMS == 3) xl[j] = (short)lo;
+    }
+#pragma unroll
+    for (int et = 0; et < 2; ++et) {
+      const int e0 = 32 * et + 16 * (g & 1);
+      const int r0 = sub * 32 + 16 * s + 4 * (g >> 1) + qq;
+      const int chunk = (e0 >> 3) + (pp >> 1);
+      const int off0 = r0 * 128 + ((chunk ^ swz(r0)) << 4) + 8 * (pp & 1);
+      const int r1 = r0 + 8;
+      const int off1 = r1 * 128 + ((chunk ^ swz(r1)) << 4) + 8 * (pp & 1);
+      const bf16x4 va = tr_read(t_hi + off0), vb = tr_read(t_hi + off1);
+      const bf16x8 th = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
+      if (TERMS == 3) {
+        const bf16x4 la = tr_read(t_lo + off0), lb = tr_read(t_lo + off1);
+        const bf16x8 tl = {la[0], la[1], la[2], la[3], lb[0], lb[1], lb[2], lb[3]};
+        out[et] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(th, xl, out[et], 0, 0, 0);
+        out[et] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tl, xh, out[et], 0, 0, 0);
+      }
+      out[et] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(th, xh, out[et], 0, 0, 0);
+    }
+  }
+}
+
+__device__ __forceinline__ void load_lane_frags(const bf16_t* hi, const bf16_t* lo, int64_t off, bool want_lo, bf16x8 (&fh)[4], bf16x8 (&fl)[4]) {
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    fh[ks] = *reinterpret_cast<const bf16x8*>(hi + off + ks * 16);
+    if (want_lo) fl[ks] = *reinterpret_cast<const bf16x8*>(lo + off + ks * 16);
+  }
+}
+
+__device__ __forceinline__ void store_grad(const BwdArgs& a, const f32x16 (&acc)[2], int64_t row_off, int half, float scale) {
+#pragma unroll
+  for (int et = 0; et < 2; ++et)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int e = 32 * et + 8 * g4 + 4 * half;
+      bf16_t hi[4], lo[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) split_bf16(acc[et][4 * g4 + j] * scale, hi[j], lo[j]);
+      *reinterpret_cast<uint2*>(a.g_hi + row_off + e) = make_uint2(pack2(hi[0], hi[1]), pack2(hi[2], hi[3]));
+      if (a.g_lo) *reinterpret_cast<uint2*>(a.g_lo + row_off + e) = make_uint2(pack2(lo[0], lo[1]), pack2(lo[2], lo[3]));
+    }
+}
+
+template <int TERMS, int MODE>
+__global__ __launch_bounds__(kThreads, 2) void attention_bwd_kernel(BwdArgs a) {
+  constexpr int NPL = TERMS == 3 ? 4 : 2;
+  constexpr int STAGE = NPL * PLANE + 512;        // + [64] lse2 and [64] delta of the streamed rows (MODE_DKV)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int bh = blockIdx.y;
+  const int b = bh / a.H, h = bh - b * a.H;
+  const int l0 = blockIdx.x * LB + wave * LW;
+  const int ll_ = lane & 31, half = lane >> 5;
+  const int d = a.H * 64;
+  const int64_t head_off = (int64_t)bh * a.S * 64;            // head-major planes
+  const int64_t rm_off = (int64_t)b * a.S * d + h * 64;        // row-major dO: + row * d
+
+  int lrow = l0 + ll_; lrow = lrow < a.S ? lrow : a.S - 1;
+  bf16x8 l1h[4], l1l[4], l2h[4], l2l[4];
+  TileSrc t1, t2;
+  float lse_l = 0.f, delta_l = 0.f;
+  if (MODE == MODE_DQ) {   // lanes: queries.  L1 = q, L2 = dO; tiles: K, V
+    load_lane_frags(a.q_hi, a.q_lo, head_off + (int64_t)lrow * 64 + half * 8, TERMS == 3, l1h, l1l);
+    load_lane_frags(a.do_hi, a.do_lo, rm_off + (int64_t)lrow * d + half * 8, TERMS == 3, l2h, l2l);
+    t1 = TileSrc{a.k_hi, a.k_lo, head_off, 64};
+    t2 = TileSrc{a.v_hi, a.v_lo, head_off, 64};
+    lse_l = a.lse2[(int64_t)bh * a.S + lrow];
+    delta_l = a.delta[(int64_t)bh * a.S + lrow];
+  } else {                 // lanes: keys.  L1 = k, L2 = v; tiles: Q, dO
+    load_lane_frags(a.k_hi, a.k_lo, head_off + (int64_t)lrow * 64 + half * 8, TERMS == 3, l1h, l1l);
+    load_lane_frags(a.v_hi, a.v_lo, head_off + (int64_t)lrow * 64 + half * 8, TERMS == 3, l2h, l2l);
+    t1 = TileSrc{a.q_hi, a.q_lo, head_off, 64};
+    t2 = TileSrc{a.do_hi, a.do_lo, rm_off, d};
+  }
+
+  f32x16 g1[2], g2[2];   // MODE_DQ: g1 = dQ^T.  MODE_DKV: g1 = dK^T, g2 = dV^T
+  g1[0] = (f32x16){}; g1[1] = (f32x16){}; g2[0] = (f32x16){}; g2[1] = (f32x16){};
+
+  const int ntiles = (a.S + TB - 1) / TB;
+  auto stage_all = [&](int tt, char* stage) {
+    stage_tiles<TERMS>(t1, t2, a.S, tt, stage, wave, lane);
+    if (MODE == MODE_DKV && threadIdx.x < 128) {
+      int r = tt * TB + (threadIdx.x & 63); r = r < a.S ? r : a.S - 1;
+      const float* src = (threadIdx.x < 64 ? a.lse2 : a.delta) + (int64_t)bh * a.S + r;
+      reinterpret_cast<float*>(stage + NPL * PLANE)[threadIdx.x] = *src;
+    }
+  };
+  stage_all(0, smem);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int tt = 0; tt < ntiles; ++tt) {
+    const char* cur = smem + (tt & 1) * STAGE;
+    if (tt + 1 < ntiles) stage_all(tt + 1, smem + ((tt + 1) & 1) * STAGE);
+    const char* t1_hi = cur;
+    const char* t1_lo = cur + PLANE;
+    const char* t2_hi = cur + (TERMS == 3 ? 2 : 1) * PLANE;
+    const char* t2_lo = cur + 3 * PLANE;
+    const float* stats = reinterpret_cast<const float*>(cur + NPL * PLANE);
+    const bool tail = (tt + 1) * TB > a.S;
+
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      // s (scores) and dp for this 32-row sub-tile: rows = streamed rows (registers), cols = lanes
+      f32x16 sacc = (f32x16){}, dpacc = (f32x16){};
+      rows_times_lane<TERMS>(sacc, t1_hi, t1_lo, sub * 32 + ll_, half, l1h, l1l);
+      rows_times_lane<TERMS>(dpacc, t2_hi, t2_lo, sub * 32 + ll_, half, l2h, l2l);
+      // MODE_DQ: s^T = K q^T (rows keys), dp^T = V dO^T.   MODE_DKV: s = Q k^T (rows queries), dp = dO v^T.
+      f32x16 pacc, dsacc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int trow = sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;     // row inside the 64-row tile
+        const float lse = MODE == MODE_DQ ? lse_l : stats[trow];
+        const float dl = MODE == MODE_DQ ? delta_l : stats[64 + trow];
+        float pv = __builtin_amdgcn_exp2f(sacc[r] * kLog2e - lse);
+        if (tail && tt * TB + trow >= a.S) pv = 0.f;                        // streamed row beyond S
+        pacc[r] = pv;
+        dsacc[r] = pv * (dpacc[r] - dl);
+      }
+      trT_times_acc<TERMS>(g1, t1_hi, t1_lo, sub, dsacc, lane);             // dQ^T += K^T dS^T   |  dK^T += Q^T dS
+      if (MODE == MODE_DKV) trT_times_acc<TERMS>(g2, t2_hi, t2_lo, sub, pacc, lane);   // dV^T += dO^T P
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  const int row = l0 + ll_;
+  if (row < a.S) {
+    const int64_t out = ((int64_t)b * a.S + row) * (3 * d) + h * 64;
+    if (MODE == MODE_DQ) {
+      store_grad(a, g1, out, half, a.qscale);
+    } else {
+      store_grad(a, g1, out + d, half, 1.0f);
+      store_grad(a, g2, out + 2 * d, half, 1.0f);
+    }
+  }
+}
+
+// delta[b, h, s] = sum_e dO[b*S+s, h*64+e] * O[b*S+s, h*64+e]   (hi + lo planes reconstructed in fp32)
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* do_hi, const bf16_t* do_lo, const bf16_t* o_hi, const bf16_t* o_lo,
+                                                         float* delta, int B, int H, int S) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;     // one thread per 8 elements; 8 threads per (row, head)
+  const int d = H * 64;
+  const int64_t total = (int64_t)B * S * d / 8;
+  float acc = 0.f;
+  if (idx < total) {
+    const bf16x8 dh = reinterpret_cast<const bf16x8*>(do_hi)[idx], oh = reinterpret_cast<const bf16x8*>(o_hi)[idx];
+    bf16x8 dl = {}, ol = {};
+    if (do_lo) { dl = reinterpret_cast<const bf16x8*>(do_lo)[idx]; ol = reinterpret_cast<const bf16x8*>(o_lo)[idx]; }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float dv = bf16_to_f32((bf16_t)dh[j]) + bf16_to_f32((bf16_t)dl[j]);
+      const float ov = bf16_to_f32((bf16_t)oh[j]) + bf16_to_f32((bf16_t)ol[j]);
+      acc += dv * ov;
+    }
+  }
+  acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4);
+  if (idx < total && (threadIdx.x & 7) == 0) {
+    const int64_t e0 = idx * 8;
+    const int64_t row = e0 / d; const int h = (int)((e0 - row * d) >> 6);
+    const int64_t b = row / S, s = row - b * S;
+    delta[(b * H + h) * S + s] = acc;
+  }
+}
+
+template <int TERMS, int MODE>
+int launch_mode(const BwdArgs& a, hipStream_t s) {
+  constexpr int lds = 2 * ((TERMS == 3 ? 4 : 2) * PLANE + 512);
+  static bool attr = false;
+  if (!attr) {
+    AWT_HIP_CHECK(hipFuncSetAttribute((const void*)attention_bwd_kernel<TERMS, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr = true;
+  }
+  dim3 grid((a.S + LB - 1) / LB, a.B * a.H);
+  hipLaunchKernelGGL((attention_bwd_kernel<TERMS, MODE>), grid, dim3(kThreads), lds, s, a);
+  AWT_HIP_CHECK(hipGetLastError());
+  return AWT_OK;
+}
+
+}  // namespace
+
+int launch_attention_bwd(awt_ctx* c, const bf16_t* q_hi, const bf16_t* q_lo, const bf16_t* k_hi, const bf16_t* k_lo,
+                         const bf16_t* v_hi, const bf16_t* v_lo, const bf16_t* o_hi, const bf16_t* o_lo, const bf16_t* do_hi,
+                         const bf16_t* do_lo, const float* lse2, float* delta, bf16_t* g_hi, bf16_t* g_lo, int B, int H, int S,
+                         float qscale, int terms, hipStream_t s) {
+  AWT_REQUIRE(B > 0 && H > 0 && S > 0 && (int64_t)B * H <= 65535, AWT_ERR_INVALID, "attention_bwd: bad shape");
+  AWT_REQUIRE(terms == 1 || terms == 3, AWT_ERR_INVALID, "attention_bwd: terms must be 1 or 3");
+  AWT_REQUIRE(q_hi && k_hi && v_hi && o_hi && do_hi && lse2 && delta && g_hi, AWT_ERR_INVALID, "attention_bwd: null argument");
+  AWT_REQUIRE(terms == 1 || (q_lo && k_lo && v_lo && o_lo && do_lo && g_lo), AWT_ERR_INVALID, "attention_bwd: lo planes required");
+  ProfScope prof(c, AWT_PROF_ATTENTION, s, 14.0 * (double)B * H * (double)S * S * 64);   // 7 products (s and dp are formed twice)
+  const int64_t n8 = (int64_t)B * S * H * 64 / 8;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, do_hi, terms == 3 ? do_lo : nullptr, o_hi,
+                     terms == 3 ? o_lo : nullptr, delta, B, H, S);
+  AWT_HIP_CHECK(hipGetLastError());
+  BwdArgs a{q_hi, q_lo, k_hi, k_lo, v_hi, v_lo, do_hi, do_lo, lse2, delta, g_hi, terms == 3 ? g_lo : nullptr, B, H, S, qscale};
+  int rc = terms == 3 ? launch_mode<3, MODE_DQ>(a, s) : launch_mode<1, MODE_DQ>(a, s);
+  if (rc) return rc;
+  return terms == 3 ? launch_mode<3, MODE_DKV>(a, s) : launch_mode<1, MODE_DKV>(a, s);
+}

@@ -116,10 +116,13 @@ struct LoraGroup {   // adapters that share one input (q/k/v share LN1's output)
   bool active = false;
   Planes a;          // [128, K_in]: rows slot * r .. slot * r + r - 1 hold adapter `slot`'s A
   Planes b;          // [N_out, kp]: columns slot * r .. hold B (pre-scaling is applied to u, not to B)
+  Planes bT;         // training: [128, N_out] = B^T  (weight of du = dy B)
+  Planes aT;         // training: [K_in, kp]  = (alpha / r) A^T  (weight of the adapter term of dx)
   int kp = 0;
 };
 struct Layer {
   Linear qkv, out, fc1, fc2;
+  Planes qkvT, outT, fc1T, fc2T;   // training: transposed copies [K, N] of the frozen weights (dX = dY W)
   float *ln1_g = nullptr, *ln1_b = nullptr, *ln2_g = nullptr, *ln2_b = nullptr;
   LoraGroup lq, lo_, l1, l2;
 };
@@ -166,7 +169,12 @@ int alloc_lora(awt_encoder* e, LoraGroup* g, int slots, int K_in, int N_out) {
   g->active = true;
   g->kp = (int)(((int64_t)slots * e->cfg.lora_rank + 63) / 64 * 64);
   int rc = alloc_planes(e, &g->a, 128, K_in); if (rc) return rc;
-  return alloc_planes(e, &g->b, N_out, g->kp);
+  rc = alloc_planes(e, &g->b, N_out, g->kp); if (rc) return rc;
+  if (e->cfg.training) {
+    rc = alloc_planes(e, &g->bT, 128, N_out); if (rc) return rc;
+    rc = alloc_planes(e, &g->aT, K_in, g->kp); if (rc) return rc;
+  }
+  return AWT_OK;
 }
 
 struct Workspace {  // per-chunk buffers carved from the caller's workspace
@@ -206,7 +214,7 @@ GemmSeg seg_plain(const bf16_t* a_hi, const bf16_t* a_lo, int64_t lda, const Pla
 }
 
 // y = x W^T (+ LoRA: [x | u] [W | B]^T with u = (alpha / r) x A^T) with the given epilogue
-int linear_with_lora(awt_encoder* e, const Workspace& w, bf16_t* const in[2], int64_t ld_in, const Linear& lin, const LoraGroup& lg,
+int linear_with_lora(awt_encoder* e, bf16_t* const u[2], bf16_t* const in[2], int64_t ld_in, const Linear& lin, const LoraGroup& lg,
                      int M, GemmEpilogue epi, GemmOut out, hipStream_t s) {
   const int terms = e->cfg.mfma_terms;
   GemmSeg segs[2];
@@ -215,10 +223,10 @@ int linear_with_lora(awt_encoder* e, const Workspace& w, bf16_t* const in[2], in
   if (lg.active) {
     GemmSeg us = seg_plain(in[0], in[1], ld_in, lg.a, 0, lin.K, M);
     GemmOut uo{};
-    uo.hi = w.u[0]; uo.lo = e->planes == 2 ? w.u[1] : nullptr; uo.ldo = lg.kp; uo.n_valid = lg.kp;
+    uo.hi = u[0]; uo.lo = u[1]; uo.ldo = lg.kp; uo.n_valid = lg.kp;
     uo.scale = e->cfg.lora_alpha / (float)e->cfg.lora_rank;
     int rc = launch_gemm(e->ctx, M, 128, &us, 1, terms, EPI_BF16, uo, s); if (rc) return rc;
-    segs[1] = seg_plain(w.u[0], e->planes == 2 ? w.u[1] : nullptr, lg.kp, lg.b, 0, lg.kp, M);
+    segs[1] = seg_plain(u[0], u[1], lg.kp, lg.b, 0, lg.kp, M);
     nseg = 2;
   }
   out.bias = lin.bias;
@@ -226,58 +234,124 @@ int linear_with_lora(awt_encoder* e, const Workspace& w, bf16_t* const in[2], in
   return launch_gemm(e->ctx, M, lin.N, segs, nseg, terms, epi, out, s);
 }
 
-int forward_chunk(awt_encoder* e, const float* mel, int Bc, float* hidden, char* ws_base, hipStream_t s) {
+// Per-layer activation buffers.  Inference: every layer reuses one set (residual stream updated in place).
+// Training: one set per layer, kept for awt_encoder_backward.
+struct LayerBufs {
+  float *x_in, *x_mid, *x_out;            // residual stream before the layer, after attention, after the MLP
+  bf16_t *ln1[2], *qkv[2], *att[2], *ln2[2], *pre[2], *ff[2], *u[2];
+  float* lse;                             // [B, H, S] or null
+};
+
+struct TrainWs {   // carved from the caller's `saved` buffer
+  std::vector<LayerBufs> layer;
+  bf16_t *a1[2], *h1[2], *ff[2];          // conv-phase scratch, MLP hidden (not needed by the q/k/v-adapter backward)
+  float* x_final;
+  // backward scratch
+  float *dx_a, *dx_b, *dln, *delta, *partial;
+  bf16_t *dxp[2], *dpre[2], *datt[2], *dqkv[2], *du[2];
+  size_t partial_bytes, bytes;
+};
+
+TrainWs carve_train(const awt_encoder* e, char* base, int B) {
   const awt_encoder_cfg& c = e->cfg;
-  const int S = c.n_ctx, T = 2 * S, d = c.d_model, f = c.ffn_dim, H = c.n_heads, terms = c.mfma_terms;
+  const size_t P = e->planes, S = c.n_ctx, T = 2 * S, d = c.d_model, f = c.ffn_dim, H = c.n_heads;
+  const size_t M = (size_t)B * S, Mt = (size_t)B * T;
+  TrainWs w{};
+  size_t off = 0;
+  auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += align_up(bytes); return p; };
+  auto planes = [&](bf16_t* (&dst)[2], size_t elems) { dst[0] = dst[1] = nullptr; for (size_t p = 0; p < P; ++p) dst[p] = (bf16_t*)take(elems * 2); };
+  w.layer.resize(c.n_layers);
+  float* x = (float*)take(M * d * 4);
+  for (int li = 0; li < c.n_layers; ++li) {
+    LayerBufs& L = w.layer[li];
+    L.x_in = x;
+    L.x_mid = (float*)take(M * d * 4);
+    L.x_out = (float*)take(M * d * 4);
+    x = L.x_out;
+    planes(L.ln1, M * d); planes(L.qkv, 3 * M * d); planes(L.att, M * d); planes(L.ln2, M * d); planes(L.pre, M * f);
+    planes(L.u, M * 128);
+    L.lse = (float*)take((size_t)B * H * S * 4);
+  }
+  w.x_final = x;
+  planes(w.ff, M * f);
+  // conv-phase scratch aliases the backward scratch (disjoint in time)
+  const size_t mark = off;
+  planes(w.a1, Mt * kConv1K); planes(w.h1, Mt * d);
+  const size_t conv_end = off;
+  off = mark;
+  w.dx_a = (float*)take(M * d * 4); w.dx_b = (float*)take(M * d * 4); w.dln = (float*)take(M * d * 4);
+  w.delta = (float*)take((size_t)B * H * S * 4);
+  planes(w.dxp, M * d); planes(w.dpre, M * f); planes(w.datt, M * d); planes(w.dqkv, 3 * M * d); planes(w.du, M * 128);
+  w.partial_bytes = outer_reduce_partial_bytes((int)M, c.lora_rank > 0 ? c.lora_rank : 1, (int)d);
+  w.partial = (float*)take(w.partial_bytes);
+  w.bytes = std::max(off, conv_end);
+  for (int li = 0; li < c.n_layers; ++li) for (int p = 0; p < 2; ++p) w.layer[li].ff[p] = w.ff[p];
+  return w;
+}
+
+// conv stem (K5-K7): mel [Bc, n_mels, T] -> residual stream x [Bc * S, d] fp32
+int conv_stem(awt_encoder* e, const float* mel, int Bc, bf16_t* const a1[2], bf16_t* const h1[2], float* x, hipStream_t s) {
+  const awt_encoder_cfg& c = e->cfg;
+  const int S = c.n_ctx, T = 2 * S, d = c.d_model, terms = c.mfma_terms;
   const int M = Bc * S, Mt = Bc * T;
-  const bool two = e->planes == 2;
-  Workspace w = carve(e, ws_base, Bc);
-  int rc;
-  // ---- conv stem (K5-K7)
-  rc = launch_im2col_conv1(e->ctx, mel, Bc, c.n_mels, T, kConv1K, w.a1[0], two ? w.a1[1] : nullptr, s); if (rc) return rc;
+  int rc = launch_im2col_conv1(e->ctx, mel, Bc, c.n_mels, T, kConv1K, a1[0], a1[1], s); if (rc) return rc;
   {
-    GemmSeg sg = seg_plain(w.a1[0], two ? w.a1[1] : nullptr, kConv1K, e->conv1.w, 0, kConv1K, Mt);
-    GemmOut o{}; o.hi = w.h1[0]; o.lo = two ? w.h1[1] : nullptr; o.ldo = d; o.bias = e->conv1.bias; o.n_valid = d;
+    GemmSeg sg = seg_plain(a1[0], a1[1], kConv1K, e->conv1.w, 0, kConv1K, Mt);
+    GemmOut o{}; o.hi = h1[0]; o.lo = h1[1]; o.ldo = d; o.bias = e->conv1.bias; o.n_valid = d;
     rc = launch_gemm(e->ctx, Mt, d, &sg, 1, terms, EPI_BF16_GELU, o, s); if (rc) return rc;
   }
-  {
-    GemmSeg sg[3];
-    for (int dt = 0; dt < 3; ++dt) {
-      sg[dt] = seg_plain(w.h1[0], two ? w.h1[1] : nullptr, d, e->conv2.w, (int64_t)dt * d, d, M);
-      sg[dt].rows_out = S; sg[dt].rows_in = T; sg[dt].row_mul = 2; sg[dt].row_add = dt - 1;
-    }
-    GemmOut o{}; o.f32 = w.x; o.ldo = d; o.bias = e->conv2.bias; o.n_valid = d; o.pos = e->pos; o.rows_pos = S;
-    rc = launch_gemm(e->ctx, M, d, sg, 3, terms, EPI_F32_GELU_POS, o, s); if (rc) return rc;
+  GemmSeg sg[3];
+  for (int dt = 0; dt < 3; ++dt) {
+    sg[dt] = seg_plain(h1[0], h1[1], d, e->conv2.w, (int64_t)dt * d, d, M);
+    sg[dt].rows_out = S; sg[dt].rows_in = T; sg[dt].row_mul = 2; sg[dt].row_add = dt - 1;
   }
-  // ---- transformer layers (K8-K13)
-  bf16_t* lnp[2] = {w.ln[0], two ? w.ln[1] : nullptr};
-  bf16_t* attp[2] = {w.att[0], two ? w.att[1] : nullptr};
-  bf16_t* ffp[2] = {w.ff[0], two ? w.ff[1] : nullptr};
+  GemmOut o{}; o.f32 = x; o.ldo = d; o.bias = e->conv2.bias; o.n_valid = d; o.pos = e->pos; o.rows_pos = S;
+  return launch_gemm(e->ctx, M, d, sg, 3, terms, EPI_F32_GELU_POS, o, s);
+}
+
+// one transformer layer (K8-K13) on the given buffers; `save` also keeps the MLP pre-activation and the softmax statistics
+int encoder_layer(awt_encoder* e, Layer& L, const LayerBufs& b, int Bc, bool save, hipStream_t s) {
+  const awt_encoder_cfg& c = e->cfg;
+  const int S = c.n_ctx, d = c.d_model, f = c.ffn_dim, H = c.n_heads, terms = c.mfma_terms;
+  const int M = Bc * S;
   const int64_t plane = (int64_t)M * d;
-  for (int li = 0; li < c.n_layers; ++li) {
-    Layer& L = e->layers[li];
-    rc = launch_layernorm(e->ctx, w.x, L.ln1_g, L.ln1_b, M, d, 1e-5f, nullptr, lnp[0], lnp[1], s); if (rc) return rc;
-    {
-      GemmOut o{}; o.hi = w.qkv[0]; o.lo = two ? w.qkv[1] : nullptr; o.scale = 0.125f; o.S = S; o.H = H; o.plane_stride = plane;
-      rc = linear_with_lora(e, w, lnp, d, L.qkv, L.lq, M, EPI_QKV, o, s); if (rc) return rc;
-    }
-    rc = launch_attention(e->ctx, w.qkv[0], two ? w.qkv[1] : nullptr, w.qkv[0] + plane, two ? w.qkv[1] + plane : nullptr,
-                          w.qkv[0] + 2 * plane, two ? w.qkv[1] + 2 * plane : nullptr, attp[0], attp[1], nullptr, Bc, H, S, terms, s);
-    if (rc) return rc;
-    {
-      GemmOut o{}; o.f32 = w.x; o.resid = w.x; o.ldo = d;
-      rc = linear_with_lora(e, w, attp, d, L.out, L.lo_, M, EPI_F32_RESID, o, s); if (rc) return rc;
-    }
-    rc = launch_layernorm(e->ctx, w.x, L.ln2_g, L.ln2_b, M, d, 1e-5f, nullptr, lnp[0], lnp[1], s); if (rc) return rc;
-    {
-      GemmOut o{}; o.hi = ffp[0]; o.lo = ffp[1]; o.ldo = f;
-      rc = linear_with_lora(e, w, lnp, d, L.fc1, L.l1, M, EPI_BF16_GELU, o, s); if (rc) return rc;
-    }
-    {
-      GemmOut o{}; o.f32 = w.x; o.resid = w.x; o.ldo = d;
-      rc = linear_with_lora(e, w, ffp, f, L.fc2, L.l2, M, EPI_F32_RESID, o, s); if (rc) return rc;
-    }
+  int rc = launch_layernorm(e->ctx, b.x_in, L.ln1_g, L.ln1_b, M, d, 1e-5f, nullptr, b.ln1[0], b.ln1[1], s); if (rc) return rc;
+  {
+    GemmOut o{}; o.hi = b.qkv[0]; o.lo = b.qkv[1]; o.scale = 0.125f; o.S = S; o.H = H; o.plane_stride = plane;
+    rc = linear_with_lora(e, b.u, b.ln1, d, L.qkv, L.lq, M, EPI_QKV, o, s); if (rc) return rc;
   }
+  rc = launch_attention(e->ctx, b.qkv[0], b.qkv[1], b.qkv[0] + plane, b.qkv[1] ? b.qkv[1] + plane : nullptr, b.qkv[0] + 2 * plane,
+                        b.qkv[1] ? b.qkv[1] + 2 * plane : nullptr, b.att[0], b.att[1], nullptr, save ? b.lse : nullptr, Bc, H, S, terms, s);
+  if (rc) return rc;
+  {
+    GemmOut o{}; o.f32 = b.x_mid; o.resid = b.x_in; o.ldo = d;
+    rc = linear_with_lora(e, b.u, b.att, d, L.out, L.lo_, M, EPI_F32_RESID, o, s); if (rc) return rc;
+  }
+  rc = launch_layernorm(e->ctx, b.x_mid, L.ln2_g, L.ln2_b, M, d, 1e-5f, nullptr, b.ln2[0], b.ln2[1], s); if (rc) return rc;
+  {
+    GemmOut o{}; o.hi = b.ff[0]; o.lo = b.ff[1]; o.ldo = f; o.hi2 = b.pre[0]; o.lo2 = b.pre[1];
+    rc = linear_with_lora(e, b.u, b.ln2, d, L.fc1, L.l1, M, save ? EPI_BF16_GELU_SAVE : EPI_BF16_GELU, o, s); if (rc) return rc;
+  }
+  GemmOut o{}; o.f32 = b.x_out; o.resid = b.x_mid; o.ldo = d;
+  return linear_with_lora(e, b.u, b.ff, f, L.fc2, L.l2, M, EPI_F32_RESID, o, s);
+}
+
+int forward_chunk(awt_encoder* e, const float* mel, int Bc, float* hidden, char* ws_base, hipStream_t s) {
+  const awt_encoder_cfg& c = e->cfg;
+  const int M = Bc * c.n_ctx, d = c.d_model;
+  const bool two = e->planes == 2;
+  Workspace w = carve(e, ws_base, Bc);
+  bf16_t* a1[2] = {w.a1[0], two ? w.a1[1] : nullptr};
+  bf16_t* h1[2] = {w.h1[0], two ? w.h1[1] : nullptr};
+  int rc = conv_stem(e, mel, Bc, a1, h1, w.x, s); if (rc) return rc;
+  LayerBufs b{};
+  b.x_in = b.x_mid = b.x_out = w.x;
+  for (int p = 0; p < 2; ++p) {
+    const bool on = p == 0 || two;
+    b.ln1[p] = b.ln2[p] = on ? w.ln[p] : nullptr; b.qkv[p] = on ? w.qkv[p] : nullptr; b.att[p] = on ? w.att[p] : nullptr;
+    b.ff[p] = on ? w.ff[p] : nullptr; b.u[p] = on ? w.u[p] : nullptr; b.pre[p] = nullptr;
+  }
+  for (int li = 0; li < c.n_layers; ++li) { rc = encoder_layer(e, e->layers[li], b, Bc, false, s); if (rc) return rc; }
   return launch_layernorm(e->ctx, w.x, e->lnf_g, e->lnf_b, M, d, 1e-5f, hidden, nullptr, nullptr, s);
 }
 
@@ -322,9 +396,11 @@ extern "C" int awt_encoder_create(awt_ctx* c, const awt_encoder_cfg* cfg, awt_en
   AWT_REQUIRE(cfg->mfma_terms == 1 || cfg->mfma_terms == 3, AWT_ERR_INVALID, "encoder_create: mfma_terms must be 1 or 3");
   AWT_REQUIRE(cfg->lora_rank >= 0 && cfg->lora_rank <= 32, AWT_ERR_INVALID, "encoder_create: lora_rank must be in 0..32");
   AWT_REQUIRE(cfg->lora_rank == 0 || cfg->lora_targets != 0, AWT_ERR_INVALID, "encoder_create: lora_rank > 0 needs lora_targets");
+  AWT_REQUIRE(!cfg->training || (cfg->lora_rank > 0 && !(cfg->lora_targets & (AWT_LORA_OUT | AWT_LORA_FC1 | AWT_LORA_FC2))), AWT_ERR_INVALID,
+              "encoder_create: training mode needs adapters, and supports them on q_proj / k_proj / v_proj only");
   awt_encoder* e = new awt_encoder();
   e->ctx = c; e->cfg = *cfg; e->planes = cfg->mfma_terms == 3 ? 2 : 1;
-  e->chunk = cfg->chunk_clips > 0 ? cfg->chunk_clips : 16;
+  e->chunk = cfg->chunk_clips > 0 ? cfg->chunk_clips : 64;
   const int d = cfg->d_model, f = cfg->ffn_dim;
   int rc = alloc_linear(e, &e->conv1, d, kConv1K);
   if (!rc) rc = alloc_linear(e, &e->conv2, d, 3 * d);
@@ -339,6 +415,12 @@ extern "C" int awt_encoder_create(awt_ctx* c, const awt_encoder_cfg* cfg, awt_en
     if (!rc) rc = alloc_linear(e, &L.out, d, d);
     if (!rc) rc = alloc_linear(e, &L.fc1, f, d);
     if (!rc) rc = alloc_linear(e, &L.fc2, d, f);
+    if (cfg->training) {
+      if (!rc) rc = alloc_planes(e, &L.qkvT, d, 3 * d);
+      if (!rc) rc = alloc_planes(e, &L.outT, d, d);
+      if (!rc) rc = alloc_planes(e, &L.fc1T, d, f);
+      if (!rc) rc = alloc_planes(e, &L.fc2T, f, d);
+    }
     float** lnp[4] = {&L.ln1_g, &L.ln1_b, &L.ln2_g, &L.ln2_b};
     for (int k = 0; k < 4 && !rc; ++k) rc = dev_alloc(e, (void**)lnp[k], (size_t)d * 4);
     if (lora && !rc && (cfg->lora_targets & (AWT_LORA_Q | AWT_LORA_K | AWT_LORA_V))) rc = alloc_lora(e, &L.lq, 3, d, 3 * d);
@@ -381,15 +463,20 @@ extern "C" int awt_encoder_set_weight(awt_encoder* e, const char* name, const fl
       return awt_fail(AWT_ERR_INVALID, std::string("set_weight: unknown parameter ") + name);
     Layer& L = e->layers[li];
     std::string rs(rest);
-    struct Proj { const char* key; Linear* lin; int row_off; int N; int K; LoraGroup* lg; int slot; uint32_t bit; };
+    struct Proj { const char* key; Linear* lin; int row_off; int N; int K; LoraGroup* lg; int slot; uint32_t bit; Planes* wT; };
     Proj projs[] = {
-        {"self_attn.q_proj", &L.qkv, 0, d, d, &L.lq, 0, AWT_LORA_Q},   {"self_attn.k_proj", &L.qkv, d, d, d, &L.lq, 1, AWT_LORA_K},
-        {"self_attn.v_proj", &L.qkv, 2 * d, d, d, &L.lq, 2, AWT_LORA_V}, {"self_attn.out_proj", &L.out, 0, d, d, &L.lo_, 0, AWT_LORA_OUT},
-        {"fc1", &L.fc1, 0, f, d, &L.l1, 0, AWT_LORA_FC1},              {"fc2", &L.fc2, 0, d, f, &L.l2, 0, AWT_LORA_FC2}};
+        {"self_attn.q_proj", &L.qkv, 0, d, d, &L.lq, 0, AWT_LORA_Q, &L.qkvT},   {"self_attn.k_proj", &L.qkv, d, d, d, &L.lq, 1, AWT_LORA_K, &L.qkvT},
+        {"self_attn.v_proj", &L.qkv, 2 * d, d, d, &L.lq, 2, AWT_LORA_V, &L.qkvT}, {"self_attn.out_proj", &L.out, 0, d, d, &L.lo_, 0, AWT_LORA_OUT, &L.outT},
+        {"fc1", &L.fc1, 0, f, d, &L.l1, 0, AWT_LORA_FC1, &L.fc1T},              {"fc2", &L.fc2, 0, d, f, &L.l2, 0, AWT_LORA_FC2, &L.fc2T}};
+    const float lscale = r > 0 ? c.lora_alpha / (float)r : 0.f;
     bool found = false;
     for (const Proj& p : projs) {
       const std::string key(p.key);
-      if (rs == key + ".weight") { found = true; rc = check_shape(name, shape, rank, {p.N, p.K}); if (!rc) rc = pack(p.lin->w, p.N, p.K, 1, p.row_off, 0); }
+      if (rs == key + ".weight") {
+        found = true; rc = check_shape(name, shape, rank, {p.N, p.K}); if (!rc) rc = pack(p.lin->w, p.N, p.K, 1, p.row_off, 0);
+        if (!rc && c.training)   // W^T: [K, N_total], this projection's columns start at row_off
+          rc = launch_pack_weight_t(e->ctx, data, p.N, p.K, p.wT->ld, 0, p.row_off, 1.0f, p.wT->hi, p.wT->lo, s);
+      }
       else if (rs == key + ".bias") {
         found = true;
         if (key == "self_attn.k_proj") return awt_fail(AWT_ERR_INVALID, "set_weight: k_proj has no bias (HF:modeling_whisper.py:279)");
@@ -398,8 +485,13 @@ extern "C" int awt_encoder_set_weight(awt_encoder* e, const char* name, const fl
         found = true;
         if (r == 0 || !(c.lora_targets & p.bit) || !p.lg->active)
           return awt_fail(AWT_ERR_STATE, std::string("set_weight: ") + name + " given but this adapter is not enabled in awt_encoder_cfg");
-        if (rs.back() == 'A') { rc = check_shape(name, shape, rank, {r, p.K}); if (!rc) rc = pack(p.lg->a, r, p.K, 1, p.slot * r, 0); }
-        else { rc = check_shape(name, shape, rank, {p.N, r}); if (!rc) rc = pack(p.lg->b, p.N, r, 1, p.row_off, p.slot * r); }
+        if (rs.back() == 'A') {
+          rc = check_shape(name, shape, rank, {r, p.K}); if (!rc) rc = pack(p.lg->a, r, p.K, 1, p.slot * r, 0);
+          if (!rc && c.training) rc = launch_pack_weight_t(e->ctx, data, r, p.K, p.lg->aT.ld, 0, p.slot * r, lscale, p.lg->aT.hi, p.lg->aT.lo, s);
+        } else {
+          rc = check_shape(name, shape, rank, {p.N, r}); if (!rc) rc = pack(p.lg->b, p.N, r, 1, p.row_off, p.slot * r);
+          if (!rc && c.training) rc = launch_pack_weight_t(e->ctx, data, p.N, r, p.lg->bT.ld, p.slot * r, p.row_off, 1.0f, p.lg->bT.hi, p.lg->bT.lo, s);
+        }
       }
       if (found) break;
     }
@@ -527,5 +619,119 @@ extern "C" int awt_op_attention(awt_ctx* c, const float* q, const float* k, cons
   for (int i = 0; i < 6; ++i) pl[i] = (bf16_t*)((char*)workspace + i * pb);
   const float* src[3] = {q, k, v};
   for (int i = 0; i < 3; ++i) { int rc = launch_split_f32(c, src[i], n, pl[2 * i], pl[2 * i + 1], s); if (rc) return rc; }
-  return launch_attention(c, pl[0], pl[1], pl[2], pl[3], pl[4], pl[5], nullptr, nullptr, o, B, H, S, terms, s);
+  return launch_attention(c, pl[0], pl[1], pl[2], pl[3], pl[4], pl[5], nullptr, nullptr, o, nullptr, B, H, S, terms, s);
+}
+
+// ------------------------------------------------------------------------------------------------ LoRA fine-tune step
+extern "C" size_t awt_encoder_train_workspace_bytes(const awt_encoder* e, int B) {
+  if (!e || B <= 0 || !e->cfg.training) return 0;
+  return carve_train(e, nullptr, B).bytes;
+}
+
+extern "C" size_t awt_encoder_lora_grad_count(const awt_encoder* e) {
+  if (!e || e->cfg.lora_rank <= 0) return 0;
+  size_t slots = 0;
+  for (uint32_t bit : {AWT_LORA_Q, AWT_LORA_K, AWT_LORA_V}) if (e->cfg.lora_targets & bit) ++slots;
+  return (size_t)e->cfg.n_layers * slots * 2 * (size_t)e->cfg.lora_rank * e->cfg.d_model;
+}
+
+extern "C" int awt_encoder_forward_train(awt_encoder* e, const float* mel, int B, int n_frames, float* hidden, void* saved,
+                                         size_t saved_bytes, void* stream) {
+  AWT_REQUIRE(e && mel && hidden && saved && B > 0, AWT_ERR_INVALID, "encoder_forward_train: bad argument");
+  AWT_REQUIRE(e->cfg.training, AWT_ERR_STATE, "encoder_forward_train: encoder was not created with cfg.training");
+  const int T = 2 * e->cfg.n_ctx;
+  if (n_frames != T)
+    return awt_fail(AWT_ERR_VALUE, "Whisper expects the mel input features to be of length " + std::to_string(T) + ", but found " +
+                                       std::to_string(n_frames) + ". Make sure to pad the input mel features to " + std::to_string(T) + ".");
+  int rc = require_weights(e); if (rc) return rc;
+  AWT_REQUIRE(saved_bytes >= awt_encoder_train_workspace_bytes(e, B), AWT_ERR_WORKSPACE, "encoder_forward_train: saved buffer too small");
+  AWT_REQUIRE(((uintptr_t)saved & 255) == 0, AWT_ERR_INVALID, "encoder_forward_train: saved buffer must be 256-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  TrainWs w = carve_train(e, (char*)saved, B);
+  rc = conv_stem(e, mel, B, w.a1, w.h1, w.layer[0].x_in, s); if (rc) return rc;
+  for (int li = 0; li < e->cfg.n_layers; ++li) { rc = encoder_layer(e, e->layers[li], w.layer[li], B, true, s); if (rc) return rc; }
+  return launch_layernorm(e->ctx, w.x_final, e->lnf_g, e->lnf_b, B * e->cfg.n_ctx, e->cfg.d_model, 1e-5f, hidden, nullptr, nullptr, s);
+}
+
+extern "C" int awt_encoder_backward(awt_encoder* e, const float* d_hidden, int B, void* saved, size_t saved_bytes, float* lora_grads,
+                                    size_t n_grads, void* stream) {
+  AWT_REQUIRE(e && d_hidden && saved && lora_grads && B > 0, AWT_ERR_INVALID, "encoder_backward: bad argument");
+  AWT_REQUIRE(e->cfg.training, AWT_ERR_STATE, "encoder_backward: encoder was not created with cfg.training");
+  AWT_REQUIRE(saved_bytes >= awt_encoder_train_workspace_bytes(e, B), AWT_ERR_WORKSPACE, "encoder_backward: saved buffer too small");
+  AWT_REQUIRE(n_grads == awt_encoder_lora_grad_count(e), AWT_ERR_INVALID, "encoder_backward: lora_grads has the wrong element count");
+  hipStream_t s = (hipStream_t)stream;
+  const awt_encoder_cfg& c = e->cfg;
+  const int S = c.n_ctx, d = c.d_model, f = c.ffn_dim, H = c.n_heads, terms = c.mfma_terms, r = c.lora_rank;
+  const int M = B * S;
+  const int64_t plane = (int64_t)M * d;
+  const float lscale = c.lora_alpha / (float)r;
+  TrainWs w = carve_train(e, (char*)saved, B);
+  const uint32_t bits[3] = {AWT_LORA_Q, AWT_LORA_K, AWT_LORA_V};
+  int nslots = 0;
+  for (uint32_t bit : bits) if (c.lora_targets & bit) ++nslots;
+  const size_t per_layer = (size_t)nslots * 2 * r * d;
+
+  // final LayerNorm
+  float* dx = w.dx_a; float* dx_other = w.dx_b;
+  int rc = launch_layernorm_bwd(e->ctx, d_hidden, w.x_final, e->lnf_g, nullptr, M, d, 1e-5f, dx, w.dxp[0], w.dxp[1], s); if (rc) return rc;
+  for (int li = c.n_layers - 1; li >= 0; --li) {
+    Layer& L = e->layers[li];
+    const LayerBufs& b = w.layer[li];
+    // ---- MLP: dpre = (dx W2) * gelu'(pre) ; dln = dpre W1 ; dx_mid = dx + LN2_bwd(dln)
+    {
+      GemmSeg sg = seg_plain(w.dxp[0], w.dxp[1], d, L.fc2T, 0, d, M);
+      GemmOut o{}; o.hi = w.dpre[0]; o.lo = w.dpre[1]; o.ldo = f; o.n_valid = f; o.pre_hi = b.pre[0]; o.pre_lo = b.pre[1];
+      rc = launch_gemm(e->ctx, M, f, &sg, 1, terms, EPI_BF16_DGELU, o, s); if (rc) return rc;
+    }
+    {
+      GemmSeg sg = seg_plain(w.dpre[0], w.dpre[1], f, L.fc1T, 0, f, M);
+      GemmOut o{}; o.f32 = w.dln; o.ldo = d; o.n_valid = d;
+      rc = launch_gemm(e->ctx, M, d, &sg, 1, terms, EPI_F32, o, s); if (rc) return rc;
+    }
+    rc = launch_layernorm_bwd(e->ctx, w.dln, b.x_mid, L.ln2_g, dx, M, d, 1e-5f, dx_other, w.dxp[0], w.dxp[1], s); if (rc) return rc;
+    std::swap(dx, dx_other);   // dx = d(loss)/d(x_mid)
+    // ---- attention: datt = dx_mid Wo ; (dq, dk, dv) = attention_bwd
+    {
+      GemmSeg sg = seg_plain(w.dxp[0], w.dxp[1], d, L.outT, 0, d, M);
+      GemmOut o{}; o.hi = w.datt[0]; o.lo = w.datt[1]; o.ldo = d; o.n_valid = d; o.scale = 1.0f;
+      rc = launch_gemm(e->ctx, M, d, &sg, 1, terms, EPI_BF16, o, s); if (rc) return rc;
+    }
+    rc = launch_attention_bwd(e->ctx, b.qkv[0], b.qkv[1], b.qkv[0] + plane, b.qkv[1] ? b.qkv[1] + plane : nullptr, b.qkv[0] + 2 * plane,
+                              b.qkv[1] ? b.qkv[1] + 2 * plane : nullptr, b.att[0], b.att[1], w.datt[0], w.datt[1], b.lse, w.delta,
+                              w.dqkv[0], w.dqkv[1], B, H, S, 0.125f, terms, s);
+    if (rc) return rc;
+    // ---- adapter gradients.  Forward: u = lscale * ln1 A^T (saved), y = ln1 W^T + b + u B^T.
+    //      dB = dy^T u ; du = dy B ; dA = lscale * du^T ln1
+    {
+      GemmSeg sg = seg_plain(w.dqkv[0], w.dqkv[1], 3 * d, L.lq.bT, 0, 3 * d, M);
+      GemmOut o{}; o.hi = w.du[0]; o.lo = w.du[1]; o.ldo = L.lq.kp; o.n_valid = L.lq.kp; o.scale = 1.0f;
+      rc = launch_gemm(e->ctx, M, 128, &sg, 1, terms, EPI_BF16, o, s); if (rc) return rc;
+    }
+    float* g = lora_grads + (size_t)li * per_layer;
+    int slot_out = 0;
+    for (int which = 0; which < 3; ++which) {
+      if (!(c.lora_targets & bits[which])) continue;
+      float* dA = g + (size_t)slot_out * 2 * r * d;
+      float* dB = dA + (size_t)r * d;
+      rc = launch_outer_reduce(e->ctx, w.du[0], w.du[1], L.lq.kp, which * r, r, b.ln1[0], b.ln1[1], d, 0, d, M, lscale, dA, d, 1,
+                               w.partial, w.partial_bytes, s);
+      if (rc) return rc;
+      rc = launch_outer_reduce(e->ctx, b.u[0], b.u[1], L.lq.kp, which * r, r, w.dqkv[0], w.dqkv[1], 3 * d, which * d, d, M, 1.0f, dB, 1, r,
+                               w.partial, w.partial_bytes, s);
+      if (rc) return rc;
+      ++slot_out;
+    }
+    if (li == 0) break;   // nothing below the first adapter needs a gradient
+    // ---- dln = [dqkv | du] [Wqkv | lscale A]  ; dx_in = dx_mid + LN1_bwd(dln)
+    {
+      GemmSeg sg[2];
+      sg[0] = seg_plain(w.dqkv[0], w.dqkv[1], 3 * d, L.qkvT, 0, 3 * d, M);
+      sg[1] = seg_plain(w.du[0], w.du[1], L.lq.kp, L.lq.aT, 0, L.lq.kp, M);
+      GemmOut o{}; o.f32 = w.dln; o.ldo = d; o.n_valid = d;
+      rc = launch_gemm(e->ctx, M, d, sg, 2, terms, EPI_F32, o, s); if (rc) return rc;
+    }
+    rc = launch_layernorm_bwd(e->ctx, w.dln, b.x_in, L.ln1_g, dx, M, d, 1e-5f, dx_other, w.dxp[0], w.dxp[1], s); if (rc) return rc;
+    std::swap(dx, dx_other);
+  }
+  return AWT_OK;
 }

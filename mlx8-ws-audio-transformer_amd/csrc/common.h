@@ -89,12 +89,16 @@ enum GemmEpilogue {
   EPI_BF16 = 2,       // out hi/lo [m, n] = (acc + bias) * scale
   EPI_BF16_GELU = 3,  // out hi/lo [m, n] = gelu(acc + bias)
   EPI_QKV = 4,        // head-major q|k|v planes, q columns scaled by `scale`
-  EPI_F32_GELU_POS = 5  // out_f32[m, n] = gelu(acc + bias) + pos[m % rows_pos, n]   (conv2 + positional table)
+  EPI_F32_GELU_POS = 5,  // out_f32[m, n] = gelu(acc + bias) + pos[m % rows_pos, n]   (conv2 + positional table)
+  EPI_BF16_GELU_SAVE = 6,  // as EPI_BF16_GELU, and the pre-activation acc + bias is also written to hi2 / lo2 (training)
+  EPI_BF16_DGELU = 7       // out hi/lo [m, n] = acc * gelu'(pre[m, n])  with pre read from pre_hi / pre_lo  (backward)
 };
 
 struct GemmOut {
   float* f32; const float* resid; int64_t ldo;
   bf16_t* hi; bf16_t* lo;                 // lo may be null when terms == 1
+  bf16_t* hi2; bf16_t* lo2;               // EPI_BF16_GELU_SAVE: pre-activation planes (same ldo)
+  const bf16_t* pre_hi; const bf16_t* pre_lo;   // EPI_BF16_DGELU: saved pre-activation planes (same ldo)
   const float* bias;                      // [N] or null
   const float* pos; int rows_pos;         // EPI_F32_GELU_POS
   float scale;                            // EPI_BF16: all columns; EPI_QKV: q columns
@@ -110,7 +114,7 @@ int launch_layernorm(awt_ctx* c, const float* x, const float* gamma, const float
                      float* out_f32, bf16_t* out_hi, bf16_t* out_lo, hipStream_t s);
 // q, k, v planes: bf16 [B, H, S, 64] (lo may be null for terms == 1); o: bf16 [B*S, H*64] hi/lo
 int launch_attention(awt_ctx* c, const bf16_t* q_hi, const bf16_t* q_lo, const bf16_t* k_hi, const bf16_t* k_lo,
-                     const bf16_t* v_hi, const bf16_t* v_lo, bf16_t* o_hi, bf16_t* o_lo, float* o_f32, int B, int H,
+                     const bf16_t* v_hi, const bf16_t* v_lo, bf16_t* o_hi, bf16_t* o_lo, float* o_f32, float* lse, int B, int H,
                      int S, int terms, hipStream_t s);
 int launch_split_f32(awt_ctx* c, const float* x, int64_t n, bf16_t* hi, bf16_t* lo, hipStream_t s);
 // weights: dst[(row_off + n) * ld + col_off + k] = scale * src[n, c, dt], k = dt * C + c (taps = 1: plain [N, C])
@@ -125,3 +129,20 @@ int logmel_generic_impl(awt_ctx* c, const float* pcm, int64_t pcm_stride, int B,
                         int hop, int n_mels, float f_min, float f_max, float log_eps, float* out, hipStream_t s);
 void awt_free_tables(awt_ctx* c);
 void awt_gemm_force_tile(int t);  // 0 auto, 128 or 256: tuning / tests
+
+// ---- backward-pass launchers
+int launch_attention_bwd(awt_ctx* c, const bf16_t* q_hi, const bf16_t* q_lo, const bf16_t* k_hi, const bf16_t* k_lo,
+                         const bf16_t* v_hi, const bf16_t* v_lo, const bf16_t* o_hi, const bf16_t* o_lo, const bf16_t* do_hi,
+                         const bf16_t* do_lo, const float* lse2, float* delta, bf16_t* g_hi, bf16_t* g_lo, int B, int H, int S,
+                         float qscale, int terms, hipStream_t s);
+// dx = dres + LayerNorm_backward(dy; x, gamma)  (fp32), plus bf16 hi/lo planes of dx for the next GEMM; dres may be null
+int launch_layernorm_bwd(awt_ctx* c, const float* dy, const float* x, const float* gamma, const float* dres, int M, int d, float eps,
+                         float* dx, bf16_t* dx_hi, bf16_t* dx_lo, hipStream_t s);
+// dst[(row_off + c) * ld + col_off + n] = scale * src[n, c]   (transposed copy of an [N, C] fp32 matrix into bf16 planes)
+int launch_pack_weight_t(awt_ctx* c, const float* src, int N, int C, int64_t ld, int row_off, int col_off, float scale, bf16_t* hi,
+                         bf16_t* lo, hipStream_t s);
+// out[j * sj + n * sn] = scale * sum_m X[m, xcol + j] * Y[m, ycol + n]   for j < r, n < ny  (LoRA dA / dB; fp32 result)
+int launch_outer_reduce(awt_ctx* c, const bf16_t* x_hi, const bf16_t* x_lo, int64_t ldx, int xcol, int r, const bf16_t* y_hi,
+                        const bf16_t* y_lo, int64_t ldy, int ycol, int ny, int M, float scale, float* out, int64_t sj, int64_t sn,
+                        float* partial, size_t partial_bytes, hipStream_t s);
+size_t outer_reduce_partial_bytes(int M, int r, int ny);

@@ -128,6 +128,157 @@ __global__ __launch_bounds__(256) void im2col_conv1_kernel(const float* __restri
   }
 }
 
+// ------------------------------------------------------------------------------------------------ LayerNorm backward
+// dx = dres + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma,  xhat = (x - mean) * rstd.
+// Statistics are recomputed from the saved LayerNorm input (fp32), one wave per row, row in registers.
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ gamma, const float* dres, int M, int d,
+                                                            float eps, float* dx, bf16_t* dx_hi, bf16_t* dx_lo) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nchunk = d >> 2;
+  const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * d);
+  const float4* dyr = reinterpret_cast<const float4*>(dy + (int64_t)row * d);
+  const float4* g4 = reinterpret_cast<const float4*>(gamma);
+  float4 v[kLnMaxChunks], g[kLnMaxChunks];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < kLnMaxChunks; ++i) {
+    const int c = lane + 64 * i;
+    v[i] = c < nchunk ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  const float mean = sum / (float)d;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < kLnMaxChunks; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunk) {
+      v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+      sq += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+  const float rstd = 1.0f / sqrtf(sq / (float)d + eps);
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < kLnMaxChunks; ++i) {
+    const int c = lane + 64 * i;
+    g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < nchunk) {
+      const float4 gy = dyr[c], gm = g4[c];
+      v[i].x *= rstd; v[i].y *= rstd; v[i].z *= rstd; v[i].w *= rstd;        // xhat
+      g[i] = make_float4(gy.x * gm.x, gy.y * gm.y, gy.z * gm.z, gy.w * gm.w);
+      s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
+      s2 += (g[i].x * v[i].x + g[i].y * v[i].y) + (g[i].z * v[i].z + g[i].w * v[i].w);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+  const float c1 = s1 / (float)d, c2 = s2 / (float)d;
+#pragma unroll
+  for (int i = 0; i < kLnMaxChunks; ++i) {
+    const int c = lane + 64 * i;
+    if (c >= nchunk) continue;
+    float y[4] = {rstd * (g[i].x - c1 - v[i].x * c2), rstd * (g[i].y - c1 - v[i].y * c2),
+                  rstd * (g[i].z - c1 - v[i].z * c2), rstd * (g[i].w - c1 - v[i].w * c2)};
+    if (dres) {
+      const float4 r = reinterpret_cast<const float4*>(dres + (int64_t)row * d)[c];
+      y[0] += r.x; y[1] += r.y; y[2] += r.z; y[3] += r.w;
+    }
+    reinterpret_cast<float4*>(dx + (int64_t)row * d)[c] = make_float4(y[0], y[1], y[2], y[3]);
+    if (dx_hi) {
+      bf16_t hi[4], lo[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) split_bf16(y[j], hi[j], lo[j]);
+      reinterpret_cast<uint2*>(dx_hi + (int64_t)row * d)[c] = make_uint2(pack2(hi[0], hi[1]), pack2(hi[2], hi[3]));
+      if (dx_lo) reinterpret_cast<uint2*>(dx_lo + (int64_t)row * d)[c] = make_uint2(pack2(lo[0], lo[1]), pack2(lo[2], lo[3]));
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ transposed weight copy
+__global__ __launch_bounds__(256) void pack_weight_t_kernel(const float* __restrict__ src, int N, int C, int64_t ld, int row_off,
+                                                            int col_off, float scale, bf16_t* hi, bf16_t* lo) {
+  __shared__ float tile[32][33];
+  const int n0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  for (int r = ty; r < 32; r += 8) {
+    const int n = n0 + r, c = c0 + tx;
+    tile[r][tx] = (n < N && c < C) ? src[(int64_t)n * C + c] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int c = c0 + r, n = n0 + tx;
+    if (c < C && n < N) {
+      bf16_t h, l; split_bf16(tile[tx][r] * scale, h, l);
+      const int64_t o = (int64_t)(row_off + c) * ld + col_off + n;
+      hi[o] = h;
+      if (lo) lo[o] = l;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ LoRA gradient reductions
+// partial[wg][j][n] = sum over the workgroup's 256-row slab of X[m, xcol + j] * Y[m, ycol + n]   (fp32 VALU; the products are
+// tiny next to the GEMMs: 2 M r d FLOP per adapter matrix).  X is the skinny operand (r <= 32 columns), staged in LDS;
+// each thread owns 4 consecutive Y columns and r x 4 accumulators.  A second kernel sums the slabs in a fixed order,
+// so the gradients are bit-reproducible run to run.
+constexpr int kOrRows = 256;
+template <int R>
+__global__ __launch_bounds__(256) void outer_reduce_kernel(const bf16_t* x_hi, const bf16_t* x_lo, int64_t ldx, int xcol,
+                                                           const bf16_t* y_hi, const bf16_t* y_lo, int64_t ldy, int ycol, int ny, int M,
+                                                           float* partial) {
+  __shared__ float xs[kOrRows][R];
+  const int m0 = blockIdx.x * kOrRows;
+  const int rows = min(kOrRows, M - m0);
+  for (int i = threadIdx.x; i < rows * R; i += 256) {
+    const int mm = i / R, j = i - mm * R;
+    const int64_t o = (int64_t)(m0 + mm) * ldx + xcol + j;
+    xs[mm][j] = bf16_to_f32(x_hi[o]) + (x_lo ? bf16_to_f32(x_lo[o]) : 0.f);
+  }
+  __syncthreads();
+  const int n = threadIdx.x * 4;
+  float acc[R][4];
+#pragma unroll
+  for (int j = 0; j < R; ++j) { acc[j][0] = acc[j][1] = acc[j][2] = acc[j][3] = 0.f; }
+  if (n < ny) {
+    for (int mm = 0; mm < rows; ++mm) {
+      const int64_t o = (int64_t)(m0 + mm) * ldy + ycol + n;
+      const uint2 yh = *reinterpret_cast<const uint2*>(y_hi + o);
+      uint2 yl = make_uint2(0u, 0u);
+      if (y_lo) yl = *reinterpret_cast<const uint2*>(y_lo + o);
+      float y[4];
+      y[0] = bf16_to_f32((bf16_t)(yh.x & 0xFFFF)) + bf16_to_f32((bf16_t)(yl.x & 0xFFFF));
+      y[1] = bf16_to_f32((bf16_t)(yh.x >> 16)) + bf16_to_f32((bf16_t)(yl.x >> 16));
+      y[2] = bf16_to_f32((bf16_t)(yh.y & 0xFFFF)) + bf16_to_f32((bf16_t)(yl.y & 0xFFFF));
+      y[3] = bf16_to_f32((bf16_t)(yh.y >> 16)) + bf16_to_f32((bf16_t)(yl.y >> 16));
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        const float xv = xs[mm][j];
+        acc[j][0] += xv * y[0]; acc[j][1] += xv * y[1]; acc[j][2] += xv * y[2]; acc[j][3] += xv * y[3];
+      }
+    }
+    float* p = partial + (int64_t)blockIdx.x * R * ny;
+#pragma unroll
+    for (int j = 0; j < R; ++j) *reinterpret_cast<float4*>(p + (int64_t)j * ny + n) = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+  }
+}
+
+__global__ __launch_bounds__(256) void outer_reduce_final_kernel(const float* partial, int nslab, int R, int r, int ny, float scale,
+                                                                 float* out, int64_t sj, int64_t sn) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= r * ny) return;
+  const int j = idx / ny, n = idx - j * ny;
+  float acc = 0.f;
+  for (int s = 0; s < nslab; ++s) acc += partial[((int64_t)s * R + j) * ny + n];
+  out[j * sj + n * sn] = acc * scale;
+}
+
 }  // namespace
 
 int launch_layernorm(awt_ctx* c, const float* x, const float* gamma, const float* beta, int M, int d, float eps,
@@ -165,6 +316,49 @@ int launch_im2col_conv1(awt_ctx* c, const float* mel, int B, int C, int T, int K
   ProfScope prof(c, AWT_PROF_OTHER, s, 0.0);
   const size_t lds = (size_t)C * (kImTile + 3) * sizeof(float);
   hipLaunchKernelGGL(im2col_conv1_kernel, dim3((T + kImTile - 1) / kImTile, B), dim3(256), lds, s, mel, C, T, K_dst, hi, lo);
+  AWT_HIP_CHECK(hipGetLastError());
+  return AWT_OK;
+}
+
+int launch_layernorm_bwd(awt_ctx* c, const float* dy, const float* x, const float* gamma, const float* dres, int M, int d, float eps,
+                         float* dx, bf16_t* dx_hi, bf16_t* dx_lo, hipStream_t s) {
+  AWT_REQUIRE(dy && x && gamma && dx, AWT_ERR_INVALID, "layernorm_bwd: null argument");
+  AWT_REQUIRE(M > 0 && d > 0 && d % 4 == 0 && d <= 64 * 4 * kLnMaxChunks, AWT_ERR_INVALID, "layernorm_bwd: d must be a multiple of 4 and <= 1024");
+  ProfScope prof(c, AWT_PROF_LAYERNORM, s, 0.0);
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, s, dy, x, gamma, dres, M, d, eps, dx, dx_hi, dx_lo);
+  AWT_HIP_CHECK(hipGetLastError());
+  return AWT_OK;
+}
+
+int launch_pack_weight_t(awt_ctx* c, const float* src, int N, int C, int64_t ld, int row_off, int col_off, float scale, bf16_t* hi,
+                         bf16_t* lo, hipStream_t s) {
+  AWT_REQUIRE(src && hi && N > 0 && C > 0 && ld >= col_off + N, AWT_ERR_INVALID, "pack_weight_t: bad shape");
+  hipLaunchKernelGGL(pack_weight_t_kernel, dim3((N + 31) / 32, (C + 31) / 32), dim3(256), 0, s, src, N, C, ld, row_off, col_off, scale, hi, lo);
+  AWT_HIP_CHECK(hipGetLastError());
+  return AWT_OK;
+}
+
+size_t outer_reduce_partial_bytes(int M, int r, int ny) {
+  const int R = r <= 8 ? 8 : (r <= 16 ? 16 : 32);
+  return (size_t)((M + kOrRows - 1) / kOrRows) * R * ny * sizeof(float);
+}
+
+int launch_outer_reduce(awt_ctx* c, const bf16_t* x_hi, const bf16_t* x_lo, int64_t ldx, int xcol, int r, const bf16_t* y_hi,
+                        const bf16_t* y_lo, int64_t ldy, int ycol, int ny, int M, float scale, float* out, int64_t sj, int64_t sn,
+                        float* partial, size_t partial_bytes, hipStream_t s) {
+  AWT_REQUIRE(x_hi && y_hi && out && partial && r > 0 && r <= 32 && ny > 0 && ny % 4 == 0 && ny <= 1024, AWT_ERR_INVALID, "outer_reduce: bad shape");
+  AWT_REQUIRE(ldy % 4 == 0 && ycol % 4 == 0, AWT_ERR_INVALID, "outer_reduce: Y columns must be 8-byte aligned");
+  AWT_REQUIRE(partial_bytes >= outer_reduce_partial_bytes(M, r, ny), AWT_ERR_WORKSPACE, "outer_reduce: partial buffer too small");
+  ProfScope prof(c, AWT_PROF_OTHER, s, 0.0);
+  const int nslab = (M + kOrRows - 1) / kOrRows;
+  const int R = r <= 8 ? 8 : (r <= 16 ? 16 : 32);
+  // X columns beyond r inside the R-wide register block read neighbouring (valid, in-row) columns and are discarded below
+  AWT_REQUIRE(xcol + R <= ldx, AWT_ERR_INVALID, "outer_reduce: X block exceeds its row");
+  if (R == 8) hipLaunchKernelGGL(outer_reduce_kernel<8>, dim3(nslab), dim3(256), 0, s, x_hi, x_lo, ldx, xcol, y_hi, y_lo, ldy, ycol, ny, M, partial);
+  else if (R == 16) hipLaunchKernelGGL(outer_reduce_kernel<16>, dim3(nslab), dim3(256), 0, s, x_hi, x_lo, ldx, xcol, y_hi, y_lo, ldy, ycol, ny, M, partial);
+  else hipLaunchKernelGGL(outer_reduce_kernel<32>, dim3(nslab), dim3(256), 0, s, x_hi, x_lo, ldx, xcol, y_hi, y_lo, ldy, ycol, ny, M, partial);
+  AWT_HIP_CHECK(hipGetLastError());
+  hipLaunchKernelGGL(outer_reduce_final_kernel, dim3((r * ny + 255) / 256), dim3(256), 0, s, partial, nslab, R, r, ny, scale, out, sj, sn);
   AWT_HIP_CHECK(hipGetLastError());
   return AWT_OK;
 }

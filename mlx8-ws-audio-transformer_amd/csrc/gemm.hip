@@ -144,8 +144,28 @@ __device__ __forceinline__ void store_out4(const GemmOut& o, int m, int n, float
       off = (int64_t)which * o.plane_stride + (((int64_t)b * o.H + h) * o.S + s) * 64 + e;
     } else {
       off = (int64_t)m * o.ldo + n;
+      if (EPI == EPI_BF16_GELU_SAVE) {
+        bf16_t ph[4], pl[4];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) v[t] = (EPI == EPI_BF16_GELU) ? gelu_erf(v[t]) : v[t] * o.scale;
+        for (int t = 0; t < 4; ++t) split_bf16(v[t], ph[t], pl[t]);
+        *reinterpret_cast<uint2*>(o.hi2 + off) = make_uint2(pack2(ph[0], ph[1]), pack2(ph[2], ph[3]));
+        if (o.lo2) *reinterpret_cast<uint2*>(o.lo2 + off) = make_uint2(pack2(pl[0], pl[1]), pack2(pl[2], pl[3]));
+      }
+      if (EPI == EPI_BF16_DGELU) {
+        const uint2 ph = *reinterpret_cast<const uint2*>(o.pre_hi + off);
+        uint2 pl = make_uint2(0u, 0u);
+        if (o.pre_lo) pl = *reinterpret_cast<const uint2*>(o.pre_lo + off);
+        const unsigned hw[2] = {ph.x, ph.y}, lw[2] = {pl.x, pl.y};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float x = bf16_to_f32((bf16_t)(hw[t >> 1] >> (16 * (t & 1)))) + bf16_to_f32((bf16_t)(lw[t >> 1] >> (16 * (t & 1))));
+          // d/dx gelu(x) = Phi(x) + x phi(x)
+          v[t] *= 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] = (EPI == EPI_BF16_GELU || EPI == EPI_BF16_GELU_SAVE) ? gelu_erf(v[t]) : v[t] * o.scale;
+      }
     }
     bf16_t hi[4], lo[4];
 #pragma unroll
@@ -316,6 +336,8 @@ int launch_gemm(awt_ctx* c, int M, int N, const GemmSeg* segs, int nseg, int ter
     case EPI_BF16_GELU: return launch_epi<EPI_BF16_GELU>(a, terms, s);
     case EPI_QKV: return launch_epi<EPI_QKV>(a, terms, s);
     case EPI_F32_GELU_POS: return launch_epi<EPI_F32_GELU_POS>(a, terms, s);
+    case EPI_BF16_GELU_SAVE: return launch_epi<EPI_BF16_GELU_SAVE>(a, terms, s);
+    case EPI_BF16_DGELU: return launch_epi<EPI_BF16_DGELU>(a, terms, s);
   }
   return awt_fail(AWT_ERR_INVALID, "gemm: unknown epilogue");
 }

@@ -39,6 +39,42 @@ class BaseModelOutput:
         return (self.last_hidden_state,)[i]
 
 
+class _EncoderLoRAFunction(torch.autograd.Function):
+    """Native forward (activations kept in a library-owned layout) and native backward to the LoRA parameters.
+    The frozen base weights and the input features get no gradient (nothing below the first adapter needs one)."""
+
+    @staticmethod
+    def forward(ctx, enc, x, *lora_params):
+        L = _lib.lib()
+        B, _, T = x.shape
+        nbytes = L.awt_encoder_train_workspace_bytes(enc._handle, B)
+        saved = _lib.workspace(nbytes, x.device)
+        out = torch.empty((B, enc.cfg.max_source_positions, enc.cfg.d_model), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(L.awt_encoder_forward_train(enc._handle, _lib.ptr(x), B, T, _lib.ptr(out), _lib.ptr(saved), saved.numel(),
+                                                   _lib.stream_handle()))
+        ctx.enc, ctx.saved, ctx.B = enc, saved, B
+        ctx.shapes = [tuple(p.shape) for p in lora_params]
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        enc, L = ctx.enc, _lib.lib()
+        d_out = d_out.to(torch.float32).contiguous()
+        n = L.awt_encoder_lora_grad_count(enc._handle)
+        flat = torch.empty(n, dtype=torch.float32, device=d_out.device)
+        with torch.cuda.device(d_out.device):
+            _lib.check(L.awt_encoder_backward(enc._handle, _lib.ptr(d_out), ctx.B, _lib.ptr(ctx.saved), ctx.saved.numel(), _lib.ptr(flat), n,
+                                              _lib.stream_handle()))
+        ctx.saved = None
+        grads, off = [], 0
+        for shp in ctx.shapes:          # library order == lora_param order: per layer, per target (q, k, v): A then B
+            k = shp[0] * shp[1]
+            grads.append(flat[off: off + k].view(shp))
+            off += k
+        return (None, None, *grads)
+
+
 class _Leaf(nn.Module):
     """Parameter holder so that state-dict keys read `<path>.weight` / `.bias` / `.lora_A` / `.lora_B`."""
 
@@ -55,15 +91,19 @@ def _attach(root: nn.Module, dotted: str, p: nn.Parameter) -> None:
 
 class NativeWhisperEncoder(nn.Module):
     def __init__(self, cfg: EncoderConfig, precision: str = "bf16x3", lora: Optional[LoraSpec] = None,
-                 device: str = "cuda", chunk_clips: int = 0, seed: Optional[int] = 0, init_profile: str = "hf"):
+                 device: str = "cuda", chunk_clips: int = 0, seed: Optional[int] = 0, init_profile: str = "hf",
+                 trainable: bool = False):
         super().__init__()
         if precision not in PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(PRECISIONS)}")
         if cfg.head_dim != 64:
             raise ValueError("the native attention kernel is specialised for head_dim 64 (every Whisper size)")
+        if trainable and (lora is None or not set(lora.targets) <= {"q_proj", "k_proj", "v_proj"}):
+            raise ValueError("trainable=True needs LoRA adapters, on q_proj / k_proj / v_proj only")
         self.cfg = cfg
         self.precision = precision
         self.lora = lora
+        self.trainable = trainable
         self.config = SimpleNamespace(d_model=cfg.d_model, encoder_layers=cfg.layers, encoder_attention_heads=cfg.heads,
                                       encoder_ffn_dim=cfg.ffn, num_mel_bins=cfg.n_mels,
                                       max_source_positions=cfg.max_source_positions)
@@ -104,7 +144,8 @@ class NativeWhisperEncoder(nn.Module):
                 bits |= _lib.LORA_BITS[t]
         cfg = _lib.EncoderCfg(self.cfg.d_model, self.cfg.layers, self.cfg.heads, self.cfg.ffn, self.cfg.n_mels,
                               self.cfg.max_source_positions, PRECISIONS[self.precision],
-                              self.lora.r if self.lora else 0, float(self.lora.alpha) if self.lora else 0.0, bits, self._chunk)
+                              self.lora.r if self.lora else 0, float(self.lora.alpha) if self.lora else 0.0, bits, self._chunk,
+                              1 if self.trainable else 0)
         out = C.c_void_p()
         with torch.cuda.device(self.device):
             _lib.check(L.awt_encoder_create(_lib.ctx(self.device), C.byref(cfg), C.byref(out)))
@@ -154,6 +195,15 @@ class NativeWhisperEncoder(nn.Module):
         B, _, T = x.shape
         self.sync_weights()
         L = _lib.lib()
+        if self.trainable and torch.is_grad_enabled():
+            # library order of the adapter gradients: per layer, per target in (q, k, v) order: A then B
+            order = [t for t in ("q_proj", "k_proj", "v_proj") if t in self.lora.targets]
+            params = []
+            for i in range(self.cfg.layers):
+                for t in order:
+                    leaf = getattr(getattr(getattr(self.layers, str(i)), "self_attn"), t)
+                    params += [leaf.lora_A, leaf.lora_B]
+            return BaseModelOutput(last_hidden_state=_EncoderLoRAFunction.apply(self, x, *params))
         ws = self._workspace(L.awt_encoder_workspace_bytes(self._handle, B))
         out = torch.empty((B, self.cfg.max_source_positions, self.cfg.d_model), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
