@@ -49,7 +49,57 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fast-mode", action="store_true")
     ap.add_argument("--cpu-clips", type=int, default=8)
+    ap.add_argument("--workload", default="encode", choices=["encode", "finetune"],
+                    help="encode (default, the headline metric) or finetune: one LoRA step = fwd + bwd + all-reduce + AdamW")
+    ap.add_argument("--lora-r", type=int, default=8)
     return ap.parse_args()
+
+
+def finetune_main(a, rank, local_rank, world, dev):
+    """BASELINE.json configs[2]/[3]: Whisper-small + LoRA (q_proj, v_proj) fine-tune step, B clips per GPU, 12 label tokens,
+    one RCCL all-reduce of the flat adapter-gradient buffer per step.  Decoder + CE are stock PyTorch ops (scope row 'next')."""
+    import torch.distributed as dist
+    from mlx8_ws_audio_transformer_amd import synth, weights as wts
+    from mlx8_ws_audio_transformer_amd.feature_extraction import logmel_whisper_device
+    from mlx8_ws_audio_transformer_amd.finetune import Seq2SeqTrainer, Seq2SeqTrainingArguments, WhisperLoRAModel
+    cfg = wts.config(a.model, a.trimmed)
+    B = a.batch
+    pcm = torch.from_numpy(synth.synth_clips_i16(B, seed=1234, first=rank * B)).to(dev)
+    model = WhisperLoRAModel(cfg, wts.LoraSpec(r=a.lora_r, alpha=16.0), precision=a.precision, device=str(dev))
+    g = torch.Generator().manual_seed(rank)
+    labels = torch.randint(0, 51864, (B, 12), generator=g); labels[:, 0] = 50258
+    args = Seq2SeqTrainingArguments(per_device_train_batch_size=B, learning_rate=1e-5, max_steps=10 ** 6, predict_with_generate=False)
+    tr = Seq2SeqTrainer(args=args, model=model)
+
+    def step():
+        feats = logmel_whisper_device(pcm, n_frames=cfg.n_frames)       # mel is part of the step, as in the encode workload
+        return tr.training_step({"input_features": feats, "labels": labels})
+
+    for _ in range(a.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "4s@16kHz clips/sec through mel+Whisper-%s LoRA fine-tune step" % a.model, "value": round(B * world * a.steps / dt, 2),
+            "unit": "clips/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "LoRA r=%d (q_proj, v_proj) fine-tune step: log-mel + encoder fwd/bwd (HIP) + decoder/CE (torch) + all-reduce + AdamW" % a.lora_r,
+                       "clips_per_gpu_per_step": B, "global_batch": B * world, "precision": a.precision, "label_tokens": 12,
+                       "adapter_grad_elems": tr.bucket.numel, "parallelism": "dp%d, one RCCL all-reduce of %.2f MB per step" % (world, tr.bucket.numel * 4 / 1e6)},
+            "last_loss": loss}))
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def timed_steps(enc, pcm, steps, world, dev):
@@ -88,6 +138,9 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
+
+    if a.workload == "finetune":
+        return finetune_main(a, rank, local_rank, world, dev)
 
     from mlx8_ws_audio_transformer_amd import _lib, synth, weights as wts
     from mlx8_ws_audio_transformer_amd.encoder import NativeWhisperEncoder
