@@ -11,7 +11,7 @@ from typing import Optional
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libawt.so")
+LIB_PATH = os.environ.get("AWT_LIB") or os.path.join(HERE, "libawt.so")   # AWT_LIB: kernel-variant A/B builds (tools/)
 HEADER_PATH = os.path.join(os.path.dirname(HERE), "include", "awt.h")
 
 AWT_OK = 0

@@ -17,6 +17,7 @@
 //   so fragment reads are bank-conflict free.
 // * 1-D grid with an XCD-aware remap: consecutive tiles of one A row-panel run on one XCD so the panel is fetched
 //   from HBM once and then served by that XCD's L2.
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -94,6 +95,30 @@ struct Stager {
       w_lo[it] = (TERMS == 3) ? sg.w_lo + woff : nullptr;
     }
   }
+  // One LDS-DMA instruction of the current K-tile (piece p of NPIECES).  Issuing the pieces one at a time between
+  // MFMA groups matters: a burst of all of them blocks the wave in VMEM issue for about as long as the transfer
+  // takes, and since instructions issue in order its MFMAs wait behind them (measured: tile time = DMA time + MFMA
+  // time for the burst form).
+  static constexpr int NPIECES = T::NP * (T::ITERS_A + T::ITERS_W);
+  template <int P>
+  __device__ __forceinline__ void stage_piece(const GemmArgs& g, char* stage_base, int wave) {
+    static_assert(P >= 0 && P < NPIECES, "piece index");
+    constexpr int plane = P % T::NP;                 // 0 = hi, 1 = lo
+    constexpr int q = P / T::NP;                     // 0 .. ITERS_A + ITERS_W - 1
+    const int koff = kk * BK;
+    if constexpr (q < T::ITERS_A) {
+      char* dst = stage_base + (q * T::THREADS + wave * 64) * 16 + plane * T::PLANE_A;
+      const bf16_t* src = plane == 0 ? a_hi[q] : a_lo[q];
+      glds16(src ? (const void*)(src + koff) : (const void*)g.zeros, dst);
+    } else {
+      constexpr int it = q - T::ITERS_A;
+      char* dst = stage_base + T::OFF_W + (it * T::THREADS + wave * 64) * 16 + plane * T::PLANE_W;
+      glds16((plane == 0 ? w_hi[it] : w_lo[it]) + koff, dst);
+    }
+  }
+  __device__ __forceinline__ void advance(const GemmArgs& g, int m0, int n0, int wave, int lane) {
+    if (++kk == nk && si + 1 < g.nseg) open_segment(g, si + 1, m0, n0, wave, lane);
+  }
   // copy the current K-tile into `stage_base`, then step to the next K-tile (opening the next segment if needed)
   __device__ __forceinline__ void stage_and_advance(const GemmArgs& g, char* stage_base, int m0, int n0, int wave, int lane) {
     const int koff = kk * BK;
@@ -101,13 +126,17 @@ struct Stager {
     for (int it = 0; it < T::ITERS_A; ++it) {
       char* dst = stage_base + (it * T::THREADS + wave * 64) * 16;
       glds16(a_hi[it] ? (const void*)(a_hi[it] + koff) : (const void*)g.zeros, dst);
+#ifndef AWT_DIAG_SKIP_LO_DMA
       if (TERMS == 3) glds16(a_lo[it] ? (const void*)(a_lo[it] + koff) : (const void*)g.zeros, dst + T::PLANE_A);
+#endif
     }
 #pragma unroll
     for (int it = 0; it < T::ITERS_W; ++it) {
       char* dst = stage_base + T::OFF_W + (it * T::THREADS + wave * 64) * 16;
       glds16(w_hi[it] + koff, dst);
+#ifndef AWT_DIAG_SKIP_LO_DMA
       if (TERMS == 3) glds16(w_lo[it] + koff, dst + T::PLANE_W);
+#endif
     }
     if (++kk == nk && si + 1 < g.nseg) open_segment(g, si + 1, m0, n0, wave, lane);
   }
@@ -209,48 +238,157 @@ __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, 2) void gemm_kernel(GemmArg
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  for (int kt = 0; kt < ktiles; ++kt) {
-    char* cur = smem + (kt & 1) * T::STAGE;
-    if (kt + 1 < ktiles) st.stage_and_advance(g, smem + ((kt + 1) & 1) * T::STAGE, m0, n0, wave, lane);
-    const char* a_hi = cur;
-    const char* a_lo = cur + T::PLANE_A;
-    const char* w_hi = cur + T::OFF_W;
-    const char* w_lo = cur + T::OFF_W + T::PLANE_W;
-#pragma unroll
-    for (int ks = 0; ks < BK / 32; ++ks) {
-      bf16x8 bh[TN], bl[TN];
+#ifndef AWT_GEMM_PIPE
+#define AWT_GEMM_PIPE 1
+#endif
+  if constexpr (TERMS == 3 && AWT_GEMM_PIPE) {
+    // ---- software-pipelined K loop (BK = 32: one MFMA k-step per K-tile).
+    // A K-tile is TM steps; step i = A row-tile i (hi, lo) x the wave's TN B fragments x 3 products = 12 MFMAs.
+    //  * the A fragments of step i + 1 are read from LDS while step i's MFMAs issue (two register sets), so only the
+    //    first reads of a tile (B fragments + A_0, right after the barrier) are exposed;
+    //  * the LDS-DMA of the NEXT K-tile is issued one piece per step, never as a burst (a burst blocks the wave in VMEM
+    //    issue and its MFMAs queue behind it);
+    //  * one barrier per K-tile, after the tile's last MFMAs.
+    static_assert(BK == 32 && (TM % 2) == 0, "pipelined loop assumes one k-step per tile and an even number of steps");
+    using ST = Stager<TERMS, BK, CFG>;
+    constexpr int PPS = (ST::NPIECES + TM - 1) / TM;     // DMA pieces per step
+    bf16x8 bh[TN], bl[TN], ah[2], al[2];
+    const int arow0 = wr * TM * 16 + frow;       // + 16 i
+    auto load_b = [&](const char* stage) {
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int row = (wc * TN + j) * 16 + frow;
-        const int off = row * (BK * 2) + (((ks * 4 + fq) ^ swz<BK>(row)) << 4);
-        bh[j] = *reinterpret_cast<const bf16x8*>(w_hi + off);
-        if (TERMS == 3) bl[j] = *reinterpret_cast<const bf16x8*>(w_lo + off);
+        const int off = row * 64 + ((fq ^ swz<32>(row)) << 4);
+        bh[j] = *reinterpret_cast<const bf16x8*>(stage + T::OFF_W + off);
+        bl[j] = *reinterpret_cast<const bf16x8*>(stage + T::OFF_W + T::PLANE_W + off);
       }
-      // A fragments four tiles at a time: keeps (TM x TN accumulators + B + 4 A) inside the 256-register budget
+    };
+    auto load_a = [&](const char* stage, int i, bf16x8& h, bf16x8& l) {
+      const int row = arow0 + 16 * i;
+      const int off = row * 64 + ((fq ^ swz<32>(row)) << 4);
+      h = *reinterpret_cast<const bf16x8*>(stage + off);
+      l = *reinterpret_cast<const bf16x8*>(stage + T::PLANE_A + off);
+    };
+    auto step = [&](auto i_t, const char* cur, char* nxt, bool has_next) {
+      constexpr int i = decltype(i_t)::value;
+      // a (free) use of this step's A fragments: the compiler's wait for them lands HERE, where they have had a whole
+      // step to arrive, instead of behind the next step's reads
+      asm volatile("" ::"v"(ah[i & 1]), "v"(al[i & 1]));
+      if constexpr (i + 1 < TM) load_a(cur, i + 1, ah[(i + 1) & 1], al[(i + 1) & 1]);
+      if (has_next) {
+        if constexpr (i * PPS < ST::NPIECES) st.template stage_piece<(i * PPS < ST::NPIECES ? i * PPS : 0)>(g, nxt, wave);
+        if constexpr (PPS > 1 && i * PPS + 1 < ST::NPIECES) st.template stage_piece<(i * PPS + 1 < ST::NPIECES ? i * PPS + 1 : 0)>(g, nxt, wave);
+      }
+      __builtin_amdgcn_sched_barrier(0);   // reads / DMA of this step are issued before its MFMAs
 #pragma unroll
-      for (int i0 = 0; i0 < TM; i0 += 4) {
-        bf16x8 ah[4], al[4];
+      for (int j = 0; j < TN; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i & 1], bl[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i & 1], bh[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i & 1], bh[j], acc[i][j], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int kt = 0; kt < ktiles; ++kt) {
+      const char* cur = smem + (kt & 1) * T::STAGE;
+      char* nxt = smem + ((kt + 1) & 1) * T::STAGE;
+      const bool has_next = kt + 1 < ktiles;
+      load_b(cur);
+      load_a(cur, 0, ah[0], al[0]);
+      static_assert(TM == 4 || TM == 8, "steps are unrolled by hand");
+      step(std::integral_constant<int, 0>{}, cur, nxt, has_next);
+      step(std::integral_constant<int, 1>{}, cur, nxt, has_next);
+      step(std::integral_constant<int, 2>{}, cur, nxt, has_next);
+      step(std::integral_constant<int, 3>{}, cur, nxt, has_next);
+      if constexpr (TM == 8) {
+        step(std::integral_constant<int, 4>{}, cur, nxt, has_next);
+        step(std::integral_constant<int, 5>{}, cur, nxt, has_next);
+        step(std::integral_constant<int, 6>{}, cur, nxt, has_next);
+        step(std::integral_constant<int, 7>{}, cur, nxt, has_next);
+      }
+      if (has_next) st.advance(g, m0, n0, wave, lane);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  } else {
+    // ---- stepped K loop: a K-tile is (BK / 32) x TM steps; step (ks, i) reads A row-tile i and issues TN (x3) MFMAs.
+    // The LDS-DMA of the NEXT K-tile is issued one piece per step instead of as a burst at the top of the tile.
+    using ST = Stager<TERMS, BK, CFG>;
+    constexpr int KS = BK / 32, STEPS = KS * TM;
+    constexpr int PPS = (ST::NPIECES + STEPS - 1) / STEPS;     // pieces per step
+    for (int kt = 0; kt < ktiles; ++kt) {
+      char* cur = smem + (kt & 1) * T::STAGE;
+      char* nxt = smem + ((kt + 1) & 1) * T::STAGE;
+      const bool has_next = kt + 1 < ktiles;
+      const char* a_hi = cur;
+      const char* a_lo = cur + T::PLANE_A;
+      const char* w_hi = cur + T::OFF_W;
+      const char* w_lo = cur + T::OFF_W + T::PLANE_W;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int row = (wr * TM + i0 + i) * 16 + frow;
+      for (int ks = 0; ks < KS; ++ks) {
+        bf16x8 bh[TN], bl[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int row = (wc * TN + j) * 16 + frow;
           const int off = row * (BK * 2) + (((ks * 4 + fq) ^ swz<BK>(row)) << 4);
-          ah[i] = *reinterpret_cast<const bf16x8*>(a_hi + off);
-          if (TERMS == 3) al[i] = *reinterpret_cast<const bf16x8*>(a_lo + off);
+          bh[j] = *reinterpret_cast<const bf16x8*>(w_hi + off);
+          if (TERMS == 3) bl[j] = *reinterpret_cast<const bf16x8*>(w_lo + off);
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
+        auto step = [&](auto i_t) {
+          constexpr int i = decltype(i_t)::value;
+#ifdef AWT_DIAG_NO_COMPUTE
+          return;
+#endif
+          bf16x8 ah, al;
+          const int row = (wr * TM + i) * 16 + frow;
+          const int off = row * (BK * 2) + (((ks * 4 + fq) ^ swz<BK>(row)) << 4);
+          ah = *reinterpret_cast<const bf16x8*>(a_hi + off);
+          if (TERMS == 3) al = *reinterpret_cast<const bf16x8*>(a_lo + off);
 #pragma unroll
           for (int j = 0; j < TN; ++j) {
+#ifndef AWT_DIAG_ONE_MFMA
             if (TERMS == 3) {
-              acc[i0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i0 + i][j], 0, 0, 0);
-              acc[i0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i0 + i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[i][j], 0, 0, 0);
             }
-            acc[i0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i0 + i][j], 0, 0, 0);
+#else
+            asm volatile("" ::"v"(al), "v"(bl[j]));
+#endif
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
           }
+        };
+        // steps with their share of the next tile's DMA pieces (compile-time piece indices)
+        auto pieces = [&](auto s_t) {
+          constexpr int sidx = decltype(s_t)::value;
+#ifdef AWT_DIAG_NO_DMA
+          if (false) {
+#else
+          if (has_next) {
+#endif
+            if constexpr (sidx * PPS + 0 < ST::NPIECES) st.template stage_piece<sidx * PPS + 0>(g, nxt, wave);
+            if constexpr (PPS > 1 && sidx * PPS + 1 < ST::NPIECES) st.template stage_piece<(sidx * PPS + 1 < ST::NPIECES ? sidx * PPS + 1 : 0)>(g, nxt, wave);
+          }
+        };
+        auto run = [&](auto ks_t) {
+          constexpr int k = decltype(ks_t)::value;
+          static_assert(TM == 4 || TM == 8, "steps are unrolled by hand");
+          pieces(std::integral_constant<int, k * TM + 0>{}); step(std::integral_constant<int, 0>{});
+          pieces(std::integral_constant<int, k * TM + 1>{}); step(std::integral_constant<int, 1>{});
+          pieces(std::integral_constant<int, k * TM + 2>{}); step(std::integral_constant<int, 2>{});
+          pieces(std::integral_constant<int, k * TM + 3>{}); step(std::integral_constant<int, 3>{});
+          if constexpr (TM == 8) {
+            pieces(std::integral_constant<int, k * TM + 4>{}); step(std::integral_constant<int, 4>{});
+            pieces(std::integral_constant<int, k * TM + 5>{}); step(std::integral_constant<int, 5>{});
+            pieces(std::integral_constant<int, k * TM + 6>{}); step(std::integral_constant<int, 6>{});
+            pieces(std::integral_constant<int, k * TM + 7>{}); step(std::integral_constant<int, 7>{});
+          }
+        };
+        if (ks == 0) run(std::integral_constant<int, 0>{});
+        else run(std::integral_constant<int, (KS > 1 ? 1 : 0)>{});
       }
+      if (has_next) st.advance(g, m0, n0, wave, lane);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
   }
 
   // epilogue: the C/D layout of the 16x16 MFMA (col = lane & 15, row = (lane >> 4) * 4 + reg) would give 2-4 byte
