@@ -31,6 +31,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_DENSE_TFLOPS = 2500.0   # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
+# operand + result bytes of the 50 GEMM launches of one step (Whisper-small, B = 64, bf16 hi + lo planes, fp32 residual):
+# per layer qkv (295 + 885 MB), out (295 + 590), fc1 (295 + 1180), fc2 (1180 + 590) = 5.31 GB; conv stem 0.2 + 1.2 + 0.3 GB
+GEMM_ALGO_BYTES_PER_STEP = 12 * 5.31e9 + 1.7e9
 ENCODER_GFLOP_PER_CLIP = {("small", False): 344.16, ("small", True): 36.30, ("tiny", False): 36.94, ("tiny", True): 3.33,
                           ("base", False): 87.37}
 
@@ -187,6 +190,17 @@ def main():
                      "mfma_issue_frac": round(terms * achieved / PEAK_BF16_DENSE_TFLOPS, 4)},
         "time_share_ms_per_step": {k: round(v[0] / a.steps, 3) for k, v in prof.items()},
     }
+    # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (tools/profile_round.sh); the committed
+    # summary of the latest profiled build is attached when it matches this workload
+    tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if os.path.exists(tpath) and a.model == "small" and not a.trimmed and a.precision == "bf16x3" and B == 64:
+        try:
+            tj = json.load(open(tpath))
+            result["roofline"]["traffic"] = round(tj["per_kernel"]["gemm_kernel"]["hbm_bytes_per_launch"])
+            result["roofline"]["traffic_note"] = "bytes per GEMM launch, FETCH_SIZE x2 (gfx950) + WRITE_SIZE, from profiles/r01_traffic.json"
+            result["roofline"]["algorithmic_bytes_per_launch"] = round(GEMM_ALGO_BYTES_PER_STEP / 50)
+        except Exception:
+            pass
     gf = ENCODER_GFLOP_PER_CLIP.get((a.model, a.trimmed))
     if gf:
         result["end_to_end_algorithmic_tflops"] = round(value * gf / 1e3, 2)

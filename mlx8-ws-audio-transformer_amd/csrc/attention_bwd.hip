@@ -148,9 +148,15 @@ __global__ __launch_bounds__(kThreads, 2) void attention_bwd_kernel(BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int bh = blockIdx.y;
+  // XCD-aware 1-D grid (see attention.hip): the blocks of one head run on one XCD and share its L2 copy of the tiles
+  const int nlb = (a.S + LB - 1) / LB;
+  const int nwg = nlb * a.B * a.H;
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int qd = nwg >> 3, rm = nwg & 7;
+  const int logical = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx;
+  const int bh = logical / nlb;
   const int b = bh / a.H, h = bh - b * a.H;
-  const int l0 = blockIdx.x * LB + wave * LW;
+  const int l0 = (logical - bh * nlb) * LB + wave * LW;
   const int ll_ = lane & 31, half = lane >> 5;
   const int d = a.H * 64;
   const int64_t head_off = (int64_t)bh * a.S * 64;            // head-major planes
@@ -272,7 +278,7 @@ int launch_mode(const BwdArgs& a, hipStream_t s) {
     AWT_HIP_CHECK(hipFuncSetAttribute((const void*)attention_bwd_kernel<TERMS, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr = true;
   }
-  dim3 grid((a.S + LB - 1) / LB, a.B * a.H);
+  dim3 grid(((a.S + LB - 1) / LB) * a.B * a.H);
   hipLaunchKernelGGL((attention_bwd_kernel<TERMS, MODE>), grid, dim3(kThreads), lds, s, a);
   AWT_HIP_CHECK(hipGetLastError());
   return AWT_OK;
@@ -284,7 +290,7 @@ int launch_attention_bwd(awt_ctx* c, const bf16_t* q_hi, const bf16_t* q_lo, con
                          const bf16_t* v_hi, const bf16_t* v_lo, const bf16_t* o_hi, const bf16_t* o_lo, const bf16_t* do_hi,
                          const bf16_t* do_lo, const float* lse2, float* delta, bf16_t* g_hi, bf16_t* g_lo, int B, int H, int S,
                          float qscale, int terms, hipStream_t s) {
-  AWT_REQUIRE(B > 0 && H > 0 && S > 0 && (int64_t)B * H <= 65535, AWT_ERR_INVALID, "attention_bwd: bad shape");
+  AWT_REQUIRE(B > 0 && H > 0 && S > 0, AWT_ERR_INVALID, "attention_bwd: bad shape");
   AWT_REQUIRE(terms == 1 || terms == 3, AWT_ERR_INVALID, "attention_bwd: terms must be 1 or 3");
   AWT_REQUIRE(q_hi && k_hi && v_hi && o_hi && do_hi && lse2 && delta && g_hi, AWT_ERR_INVALID, "attention_bwd: null argument");
   AWT_REQUIRE(terms == 1 || (q_lo && k_lo && v_lo && o_lo && do_lo && g_lo), AWT_ERR_INVALID, "attention_bwd: lo planes required");

@@ -1,0 +1,43 @@
+#!/bin/bash
+# Round profile of the default bench workload: kernel-trace stats + HBM traffic counters (separate PMC passes).
+# Usage (GPU box): bash tools/profile_round.sh r01
+cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
+tag=${1:-r01}
+out=gpurun_out/prof_$tag; rm -rf $out; mkdir -p $out
+args="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fast-mode"
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $args > $out/trace.log 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout -k 10 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc_$c -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-fast-mode > $out/pmc_$c.log 2>&1
+done
+python3 - $out $tag <<'PY'
+import csv, glob, json, sys, collections
+out, tag = sys.argv[1], sys.argv[2]
+def short(n):
+    for k in ("gemm_kernel", "attention_kernel", "layernorm_kernel", "logmel_stage1", "logmel_finalize", "im2col"):
+        if k in n: return k
+    return None
+res = collections.defaultdict(lambda: collections.defaultdict(list))
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    f = glob.glob(f"{out}/pmc_{c}/**/*counter_collection.csv", recursive=True)
+    if not f: continue
+    rows = list(csv.DictReader(open(f[0])))
+    ids = sorted({int(r["Dispatch_Id"]) for r in rows})
+    half = ids[len(ids) // 2] if ids else 0          # second half = the timed step (first half is the warm-up step)
+    for r in rows:
+        k = short(r["Kernel_Name"])
+        if k and r["Counter_Name"] == c and int(r["Dispatch_Id"]) >= half:
+            res[k][c].append(float(r["Counter_Value"]))
+summary = {}
+for k, d in res.items():
+    n = max(len(v) for v in d.values())
+    fetch_kb = sum(d.get("FETCH_SIZE", [])); write_kb = sum(d.get("WRITE_SIZE", []))
+    # gfx950: FETCH_SIZE counts 64 B per 128 B request of a wide coalesced stream -> x2 (MI355X_MICROARCH.md, HBM section)
+    summary[k] = {"launches_per_step": n, "fetch_bytes_per_launch_corrected": fetch_kb * 1024 * 2 / max(n, 1),
+                  "write_bytes_per_launch": write_kb * 1024 / max(n, 1),
+                  "hbm_bytes_per_launch": (fetch_kb * 2 + write_kb) * 1024 / max(n, 1)}
+json.dump({"tag": tag, "workload": "bench.py default (Whisper-small, parity, B=64, bf16x3)", "per_kernel": summary,
+           "note": "FETCH_SIZE x2 per the gfx950 correction; counters from separate --pmc passes"}, open(f"{out}/traffic.json", "w"), indent=1)
+print(json.dumps(summary, indent=1))
+PY
+cp $(find $out/trace -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv
+head -12 $out/kernel_stats.csv | cut -c1-160
