@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--workload", default="encode", choices=["encode", "finetune"],
                     help="encode (default, the headline metric) or finetune: one LoRA step = fwd + bwd + all-reduce + AdamW")
     ap.add_argument("--lora-r", type=int, default=8)
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL, the real multi-GPU path) or gloo (rehearsal of the N > 1 code path on one GPU: every rank on cuda:0)")
     return ap.parse_args()
 
 
@@ -135,12 +137,15 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", local_rank if a.dist_backend == "nccl" else 0)
     torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if a.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     if a.workload == "finetune":
         return finetune_main(a, rank, local_rank, world, dev)
