@@ -274,8 +274,14 @@ __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, 2) void gemm_kernel(GemmArg
       // a (free) use of this step's A fragments: the compiler's wait for them lands HERE, where they have had a whole
       // step to arrive, instead of behind the next step's reads
       asm volatile("" ::"v"(ah[i & 1]), "v"(al[i & 1]));
+#ifndef AWT_DIAG_NO_LDSREAD   // AWT_DIAG_*: timing-only builds of tools/build_variants.sh (wrong results), never shipped
       if constexpr (i + 1 < TM) load_a(cur, i + 1, ah[(i + 1) & 1], al[(i + 1) & 1]);
+#endif
+#ifdef AWT_DIAG_NO_DMA
+      if (false) {
+#else
       if (has_next) {
+#endif
         if constexpr (i * PPS < ST::NPIECES) st.template stage_piece<(i * PPS < ST::NPIECES ? i * PPS : 0)>(g, nxt, wave);
         if constexpr (PPS > 1 && i * PPS + 1 < ST::NPIECES) st.template stage_piece<(i * PPS + 1 < ST::NPIECES ? i * PPS + 1 : 0)>(g, nxt, wave);
       }
@@ -292,8 +298,12 @@ __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, 2) void gemm_kernel(GemmArg
       const char* cur = smem + (kt & 1) * T::STAGE;
       char* nxt = smem + ((kt + 1) & 1) * T::STAGE;
       const bool has_next = kt + 1 < ktiles;
+#ifndef AWT_DIAG_NO_LDSREAD
       load_b(cur);
       load_a(cur, 0, ah[0], al[0]);
+#else
+      if (kt == 0) { load_b(cur); load_a(cur, 0, ah[0], al[0]); ah[1] = ah[0]; al[1] = al[0]; }
+#endif
       static_assert(TM == 4 || TM == 8, "steps are unrolled by hand");
       step(std::integral_constant<int, 0>{}, cur, nxt, has_next);
       step(std::integral_constant<int, 1>{}, cur, nxt, has_next);
@@ -306,8 +316,10 @@ __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, 2) void gemm_kernel(GemmArg
         step(std::integral_constant<int, 7>{}, cur, nxt, has_next);
       }
       if (has_next) st.advance(g, m0, n0, wave, lane);
+#ifndef AWT_DIAG_NO_BARRIER
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
+#endif
     }
   } else {
     // ---- stepped K loop: a K-tile is (BK / 32) x TM steps; step (ks, i) reads A row-tile i and issues TN (x3) MFMAs.
