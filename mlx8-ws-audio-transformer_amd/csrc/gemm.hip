@@ -68,6 +68,9 @@ struct Stager {
   int si, kk, nk;
 
   __device__ __forceinline__ void open_segment(const GemmArgs& g, int seg, int m0, int n0, int wave, int lane) {
+#ifdef AWT_DIAG_SAME_TILE   // every workgroup streams the same operand tiles: 100 % L2 hits (timing-only)
+    m0 = 0; n0 = 0;
+#endif
     si = seg; kk = 0;
     const GemmSeg& sg = g.seg[seg];
     nk = sg.K / BK;
