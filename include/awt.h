@@ -154,12 +154,13 @@ size_t awt_op_attention_workspace_bytes(int B, int H, int S);
 
 /* ------------------------------------------------------------------------------------------------------
  * In-library kernel timing with HIP events on the caller's stream (bench.py's `roofline` leg).
- * awt_prof_enable(c, 1) makes every launch of the kernel classes below record an event pair;
+ * awt_prof_enable(c, mask) makes every launch of the kernel classes whose bit (1 << AWT_PROF_x) is set in `mask`
+ * record an event pair (mask 0 = off);
  * awt_prof_collect synchronises the events and returns accumulated milliseconds and launch count
  * for one class, then resets that class. */
 enum { AWT_PROF_LOGMEL = 0, AWT_PROF_GEMM = 1, AWT_PROF_ATTENTION = 2, AWT_PROF_LAYERNORM = 3, AWT_PROF_OTHER = 4,
        AWT_PROF_NCLASSES = 5 };
-int awt_prof_enable(awt_ctx* c, int on);
+int awt_prof_enable(awt_ctx* c, int mask);
 int awt_prof_collect(awt_ctx* c, int klass, double* total_ms, int64_t* launches, double* flops);
 
 #ifdef __cplusplus

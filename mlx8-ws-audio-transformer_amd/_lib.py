@@ -133,8 +133,13 @@ def workspace(nbytes: int, device) -> torch.Tensor:
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
 
-def prof_enable(on: bool) -> None:
-    check(lib().awt_prof_enable(ctx(), 1 if on else 0))
+def prof_enable(on, classes=None) -> None:
+    """Event-time the given kernel classes (names from PROF_CLASSES; default all) or switch timing off."""
+    mask = 0
+    if on:
+        for k in (classes or PROF_CLASSES):
+            mask |= 1 << PROF_CLASSES[k]
+    check(lib().awt_prof_enable(ctx(), mask))
 
 
 def prof_collect(klass: str):

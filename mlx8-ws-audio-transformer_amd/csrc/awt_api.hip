@@ -40,7 +40,7 @@ void awt_prof_end(awt_ctx* c, int klass, hipStream_t s) {
 extern "C" int awt_prof_enable(awt_ctx* c, int on) {
   AWT_REQUIRE(c, AWT_ERR_INVALID, "prof_enable: null ctx");
   if (!c->prof) c->prof = new awt_prof_state();
-  c->prof_on = on ? 1 : 0;
+  c->prof_on = on;   // bit k enables kernel class k (AWT_PROF_*)
   return AWT_OK;
 }
 extern "C" int awt_prof_collect(awt_ctx* c, int klass, double* total_ms, int64_t* launches, double* flops) {

@@ -67,9 +67,9 @@ void awt_prof_end(awt_ctx* c, int klass, hipStream_t s);
 struct ProfScope {
   awt_ctx* c; int klass; hipStream_t s;
   ProfScope(awt_ctx* c_, int k, hipStream_t s_, double flops = 0.0) : c(c_), klass(k), s(s_) {
-    if (c && c->prof_on) awt_prof_begin(c, klass, s, flops);
+    if (c && (c->prof_on >> klass) & 1) awt_prof_begin(c, klass, s, flops);
   }
-  ~ProfScope() { if (c && c->prof_on) awt_prof_end(c, klass, s); }
+  ~ProfScope() { if (c && (c->prof_on >> klass) & 1) awt_prof_end(c, klass, s); }
 };
 
 // ---------------------------------------------------------------- kernel launchers (defined in the .hip files)

@@ -12,7 +12,7 @@ for prec in ["bf16x3", "bf16"]:
         x = torch.randn(m, k, device="cuda")
         w = torch.randn(n, k, device="cuda") * k ** -0.5
         ops.linear(x, w, None, prec)
-        _lib.prof_enable(True); _lib.prof_collect("gemm")
+        _lib.prof_enable(True, ["gemm"]); _lib.prof_collect("gemm")
         for _ in range(3):
             ops.linear(x, w, None, prec)
         ms, cnt, fl = _lib.prof_collect("gemm"); _lib.prof_enable(False)
