@@ -1,7 +1,8 @@
 // Flash-style multi-head self-attention forward (K10) for head_dim 64, no mask -- gfx950.
 //
 //   O[b, s, h, :] = softmax_k( q[b,h,s,:] . k[b,h,k,:] ) v[b,h,k,:]      q is pre-scaled by head_dim^-1/2 in the QKV
-//   epilogue, as the reference scales q BEFORE q k^T (HF:modeling_whisper.py:309, 215-238).
+//   epilogue, as the reference scales q BEFORE q k^T (HF:modeling_whisper.py:309, 215-238), and additionally by
+//   log2(e): the q planes this kernel reads hold q * log2(e), so scores are in log2 units and exp is a bare v_exp_f32.
 //
 // Structure (per workgroup: 4 waves x 32 query rows = 128 queries of one (batch, head); K/V tiles of 64 keys):
 //  * "swapped" first product  S^T = K Q^T  on v_mfma_f32_32x32x16_bf16: the 32x32 result has the QUERY on the lane
@@ -14,6 +15,7 @@
 //  * TERMS = 3 runs both products in split-bf16 (q, k, v and P as hi + lo planes, three MFMAs per fragment pair).
 //  * fp32 running max / sum / output accumulators; S = 1500 is not a multiple of 64: tail keys are masked,
 //    tail rows clamped on load and skipped on store.
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -23,7 +25,6 @@ constexpr int QW = 32;            // queries per wave
 constexpr int QB = 128;           // queries per workgroup
 constexpr int KB = 64;            // keys per tile
 constexpr int PLANE = KB * 64 * 2;  // 8 KiB: [64 keys][64 dims] bf16
-constexpr float kLog2e = 1.4426950408889634f;
 
 struct AttnArgs {
   const bf16_t *q_hi, *q_lo, *k_hi, *k_lo, *v_hi, *v_lo;
@@ -97,12 +98,28 @@ __global__ __launch_bounds__(kThreads, 2) void attention_kernel(AttnArgs a) {
   oacc[0] = (f32x16){}; oacc[1] = (f32x16){};
   float m_run = -1.0e30f, l_run = 0.f;   // running max (log2 domain) and this half-wave's partial row sum
 
+  // ---- loop-invariant LDS byte offsets (everything else is an immediate): the swizzle term (row >> 1) & 7 does not
+  // change when a row moves by 16, so sub-tiles / k-steps / dim-tiles differ by constants or by one XOR bit.
+  //   K fragment (row = 32 kt2 + ql, chunk 2 ks + half):  koff[ks] + 4096 kt2
+  //   V^T blocks (key0 = 32 kt2 + 16 s + 4 (g >> 1) + qq, chunk 4 et + cc):  dim-tile et toggles chunk bit 2 (byte bit 6),
+  //   the +8-key block adds 1024 and toggles it back:  off0(et) = voff ^ (64 et),  off1(et) = (voff ^ 64 ^ (64 et)) + 1024
+  int koff[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) koff[ks] = ql * 128 + (((2 * ks + half) ^ swz(ql)) << 4);
+  const int g = lane >> 4, li = lane & 15, qq = li >> 2, pp = li & 3;
+  const int vkey = 4 * (g >> 1) + qq;
+  const int voff = vkey * 128 + (((2 * (g & 1) + (pp >> 1)) ^ swz(vkey)) << 4) + 8 * (pp & 1);
+  const int voffx = voff ^ 64;
+
   const int ntiles = (a.S + KB - 1) / KB;
   stage_kv<TERMS>(a, head_off, 0, smem, wave, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  for (int kt = 0; kt < ntiles; ++kt) {
+  // One K/V tile.  TAIL (compile time) masks keys >= S; it is instantiated only for the last tile, so full tiles carry no
+  // compare / select instructions (they were a quarter of the loop's VALU work, and this loop is VALU-bound).
+  auto tile = [&](auto tail_t, int kt) {
+    constexpr bool TAIL = decltype(tail_t)::value;
     const char* cur = smem + (kt & 1) * STAGE;
     if (kt + 1 < ntiles) stage_kv<TERMS>(a, head_off, kt + 1, smem + ((kt + 1) & 1) * STAGE, wave, lane);
     const char* k_hi = cur;
@@ -110,15 +127,14 @@ __global__ __launch_bounds__(kThreads, 2) void attention_kernel(AttnArgs a) {
     const char* v_hi = cur + (TERMS == 3 ? 2 : 1) * PLANE;
     const char* v_lo = cur + 3 * PLANE;
 
-    // ---- S^T = K Q^T : two 32-key sub-tiles, rows = keys, cols (lanes) = queries
+    // ---- S^T = K Q^T : two 32-key sub-tiles, rows = keys, cols (lanes) = queries; q carries log2(e), so S is in log2 units
     f32x16 sacc[2];
 #pragma unroll
     for (int kt2 = 0; kt2 < 2; ++kt2) {
       sacc[kt2] = (f32x16){};
-      const int row = kt2 * 32 + ql;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        const int off = row * 128 + (((2 * ks + half) ^ swz(row)) << 4);
+        const int off = koff[ks] + kt2 * 4096;
         const bf16x8 kh = *reinterpret_cast<const bf16x8*>(k_hi + off);
         if (TERMS == 3) {
           const bf16x8 kl = *reinterpret_cast<const bf16x8*>(k_lo + off);
@@ -129,20 +145,17 @@ __global__ __launch_bounds__(kThreads, 2) void attention_kernel(AttnArgs a) {
       }
     }
 
-    // ---- online softmax (log2 domain). C/D layout 32x32: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 half
-    const bool tail = (kt + 1) * KB > a.S;
+    // ---- online softmax.  C/D layout 32x32: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 half
     float tmax = -1.0e30f;
 #pragma unroll
     for (int kt2 = 0; kt2 < 2; ++kt2)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float t = sacc[kt2][r] * kLog2e;
-        if (tail) {
+        if (TAIL) {
           const int key = kt * KB + kt2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          t = key < a.S ? t : -1.0e30f;
+          sacc[kt2][r] = key < a.S ? sacc[kt2][r] : -1.0e30f;
         }
-        sacc[kt2][r] = t;
-        tmax = fmaxf(tmax, t);
+        tmax = fmaxf(tmax, sacc[kt2][r]);
       }
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
     const float m_new = fmaxf(m_run, tmax);
@@ -165,29 +178,25 @@ __global__ __launch_bounds__(kThreads, 2) void attention_kernel(AttnArgs a) {
 
     // ---- O^T += V^T P^T : P registers 8 s .. 8 s + 7 of a sub-tile are the B fragment of k-step s;
     //      element j of lane-half `half` is key 16 s + 8 (j >> 2) + 4 half + (j & 3) of that sub-tile.
+    //      V^T fragments come from the transpose read: 16-lane group g covers dims 16 (g & 1) .. + 15 of the dim-tile for
+    //      lane-half g >> 1; lane 4 qq + pp of the group supplies row (key) qq, columns 4 pp .. 4 pp + 3.
 #pragma unroll
     for (int kt2 = 0; kt2 < 2; ++kt2)
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
+      for (int s2 = 0; s2 < 2; ++s2) {
         bf16x8 ph, pl;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           bf16_t hi, lo;
-          split_bf16(sacc[kt2][8 * s + j], hi, lo);
+          split_bf16(sacc[kt2][8 * s2 + j], hi, lo);
           ph[j] = (short)hi;
           if (TERMS == 3) pl[j] = (short)lo;
         }
-        // V^T fragment via the transpose read: 16-lane group g = lane >> 4 covers dims 16 (g & 1) .. + 15 of the
-        // e-tile for lane-half g >> 1; lane i = 4 qq + pp of the group supplies row (key) qq, columns 4 pp .. 4 pp + 3.
-        const int g = lane >> 4, i = lane & 15, qq = i >> 2, pp = i & 3;
 #pragma unroll
         for (int et = 0; et < 2; ++et) {
-          const int e0 = 32 * et + 16 * (g & 1);
-          const int key0 = kt2 * 32 + 16 * s + 4 * (g >> 1) + qq;
-          const int chunk = (e0 >> 3) + (pp >> 1);
-          const int off0 = key0 * 128 + ((chunk ^ swz(key0)) << 4) + 8 * (pp & 1);
-          const int key1 = key0 + 8;
-          const int off1 = key1 * 128 + ((chunk ^ swz(key1)) << 4) + 8 * (pp & 1);
+          const int cst = kt2 * 4096 + s2 * 2048;
+          const int off0 = (et == 0 ? voff : voffx) + cst;
+          const int off1 = (et == 0 ? voffx : voff) + cst + 1024;
           const bf16x4 va = tr_read(v_hi + off0), vb = tr_read(v_hi + off1);
           const bf16x8 vh = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
           if (TERMS == 3) {
@@ -201,7 +210,10 @@ __global__ __launch_bounds__(kThreads, 2) void attention_kernel(AttnArgs a) {
       }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-  }
+  };
+  for (int kt = 0; kt + 1 < ntiles; ++kt) tile(std::false_type{}, kt);
+  if (a.S % KB) tile(std::true_type{}, ntiles - 1);
+  else tile(std::false_type{}, ntiles - 1);
 
   // ---- normalise and store: lane holds query (lane & 31), dims (r & 3) + 8 (r >> 2) + 4 half of each e-tile
   const float l_tot = l_run + __shfl_xor(l_run, 32);

@@ -1,6 +1,6 @@
 // Flash-style attention backward (part of K14) for head_dim 64, no mask -- gfx950.
 //
-// Given q (pre-scaled), k, v, the forward's log-sum-exp (log2 domain), dO and delta = rowsum(dO * O):
+// Given q (pre-scaled by head_dim^-1/2 and by log2(e), as attention.hip stores it), k, v, the forward's log-sum-exp (log2 domain), dO and delta = rowsum(dO * O):
 //   P = exp2(s log2e - lse2),   dV = P^T dO,   dP = dO V^T,   dS = P (dP - delta),   dQ = dS K,   dK = dS^T Q.
 // P is recomputed from the saved row statistics instead of storing the S x S scores.
 //
@@ -23,7 +23,6 @@ constexpr int LW = 32;            // lane-resident rows per wave
 constexpr int LB = 128;           // ... per workgroup
 constexpr int TB = 64;            // streamed rows per tile
 constexpr int PLANE = TB * 64 * 2;
-constexpr float kLog2e = 1.4426950408889634f;
 
 enum { MODE_DQ = 0, MODE_DKV = 1 };
 
@@ -219,7 +218,7 @@ __global__ __launch_bounds__(kThreads, 2) void attention_bwd_kernel(BwdArgs a) {
         const int trow = sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;     // row inside the 64-row tile
         const float lse = MODE == MODE_DQ ? lse_l : stats[trow];
         const float dl = MODE == MODE_DQ ? delta_l : stats[64 + trow];
-        float pv = __builtin_amdgcn_exp2f(sacc[r] * kLog2e - lse);
+        float pv = __builtin_amdgcn_exp2f(sacc[r] - lse);   // q planes carry log2(e): scores are already in log2 units
         if (tail && tt * TB + trow >= a.S) pv = 0.f;                        // streamed row beyond S
         pacc[r] = pv;
         dsacc[r] = pv * (dpacc[r] - dl);
@@ -237,7 +236,7 @@ __global__ __launch_bounds__(kThreads, 2) void attention_bwd_kernel(BwdArgs a) {
     if (MODE == MODE_DQ) {
       store_grad(a, g1, out, half, a.qscale);
     } else {
-      store_grad(a, g1, out + d, half, 1.0f);
+      store_grad(a, g1, out + d, half, 0.6931471805599453f);   // dK = dS^T q and the stored q is q * log2(e)
       store_grad(a, g2, out + 2 * d, half, 1.0f);
     }
   }

@@ -317,7 +317,8 @@ int encoder_layer(awt_encoder* e, Layer& L, const LayerBufs& b, int Bc, bool sav
   const int64_t plane = (int64_t)M * d;
   int rc = launch_layernorm(e->ctx, b.x_in, L.ln1_g, L.ln1_b, M, d, 1e-5f, nullptr, b.ln1[0], b.ln1[1], s); if (rc) return rc;
   {
-    GemmOut o{}; o.hi = b.qkv[0]; o.lo = b.qkv[1]; o.scale = 0.125f; o.S = S; o.H = H; o.plane_stride = plane;
+    GemmOut o{}; o.hi = b.qkv[0]; o.lo = b.qkv[1]; o.scale = 0.125f * 1.4426950408889634f;   // head_dim^-1/2 and log2(e): see attention.hip
+    o.S = S; o.H = H; o.plane_stride = plane;
     rc = linear_with_lora(e, b.u, b.ln1, d, L.qkv, L.lq, M, EPI_QKV, o, s); if (rc) return rc;
   }
   rc = launch_attention(e->ctx, b.qkv[0], b.qkv[1], b.qkv[0] + plane, b.qkv[1] ? b.qkv[1] + plane : nullptr, b.qkv[0] + 2 * plane,
@@ -593,8 +594,8 @@ extern "C" int awt_op_linear(awt_ctx* c, const float* x, const float* w, const f
   bf16_t* xl = (bf16_t*)base;                 base += align_up((size_t)M * K * 2);
   bf16_t* wh = (bf16_t*)base;                 base += align_up((size_t)N * K * 2);
   bf16_t* wl = (bf16_t*)base;
-  int rc = launch_split_f32(c, x, (int64_t)M * K, xh, xl, s); if (rc) return rc;
-  rc = launch_split_f32(c, w, (int64_t)N * K, wh, wl, s); if (rc) return rc;
+  int rc = launch_split_f32(c, x, (int64_t)M * K, 1.0f, xh, xl, s); if (rc) return rc;
+  rc = launch_split_f32(c, w, (int64_t)N * K, 1.0f, wh, wl, s); if (rc) return rc;
   GemmSeg sg{};
   sg.a_hi = xh; sg.a_lo = xl; sg.lda = K; sg.w_hi = wh; sg.w_lo = wl; sg.ldw = K; sg.K = K;
   sg.rows_out = M; sg.rows_in = M; sg.row_mul = 1; sg.row_add = 0;
@@ -618,7 +619,9 @@ extern "C" int awt_op_attention(awt_ctx* c, const float* q, const float* k, cons
   bf16_t* pl[6];
   for (int i = 0; i < 6; ++i) pl[i] = (bf16_t*)((char*)workspace + i * pb);
   const float* src[3] = {q, k, v};
-  for (int i = 0; i < 3; ++i) { int rc = launch_split_f32(c, src[i], n, pl[2 * i], pl[2 * i + 1], s); if (rc) return rc; }
+  for (int i = 0; i < 3; ++i) {   // the kernel expects q * log2(e)
+    int rc = launch_split_f32(c, src[i], n, i == 0 ? 1.4426950408889634f : 1.0f, pl[2 * i], pl[2 * i + 1], s); if (rc) return rc;
+  }
   return launch_attention(c, pl[0], pl[1], pl[2], pl[3], pl[4], pl[5], nullptr, nullptr, o, nullptr, B, H, S, terms, s);
 }
 

@@ -116,7 +116,7 @@ int launch_layernorm(awt_ctx* c, const float* x, const float* gamma, const float
 int launch_attention(awt_ctx* c, const bf16_t* q_hi, const bf16_t* q_lo, const bf16_t* k_hi, const bf16_t* k_lo,
                      const bf16_t* v_hi, const bf16_t* v_lo, bf16_t* o_hi, bf16_t* o_lo, float* o_f32, float* lse, int B, int H,
                      int S, int terms, hipStream_t s);
-int launch_split_f32(awt_ctx* c, const float* x, int64_t n, bf16_t* hi, bf16_t* lo, hipStream_t s);
+int launch_split_f32(awt_ctx* c, const float* x, int64_t n, float scale, bf16_t* hi, bf16_t* lo, hipStream_t s);
 // weights: dst[(row_off + n) * ld + col_off + k] = scale * src[n, c, dt], k = dt * C + c (taps = 1: plain [N, C])
 int launch_pack_weight(awt_ctx* c, const float* src, int N, int C, int taps, int64_t ld, int row_off, int col_off, float scale,
                        bf16_t* hi, bf16_t* lo, hipStream_t s);

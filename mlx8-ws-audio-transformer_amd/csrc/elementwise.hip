@@ -62,11 +62,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------ fp32 -> hi / lo planes
-__global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ x, int64_t n4, bf16_t* hi, bf16_t* lo) {
+__global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ x, int64_t n4, float scale, bf16_t* hi, bf16_t* lo) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
     const float4 v = reinterpret_cast<const float4*>(x)[i];
     bf16_t h[4], l[4];
-    split_bf16(v.x, h[0], l[0]); split_bf16(v.y, h[1], l[1]); split_bf16(v.z, h[2], l[2]); split_bf16(v.w, h[3], l[3]);
+    split_bf16(v.x * scale, h[0], l[0]); split_bf16(v.y * scale, h[1], l[1]); split_bf16(v.z * scale, h[2], l[2]); split_bf16(v.w * scale, h[3], l[3]);
     reinterpret_cast<uint2*>(hi)[i] = make_uint2(pack2(h[0], h[1]), pack2(h[2], h[3]));
     if (lo) reinterpret_cast<uint2*>(lo)[i] = make_uint2(pack2(l[0], l[1]), pack2(l[2], l[3]));
   }
@@ -291,12 +291,12 @@ int launch_layernorm(awt_ctx* c, const float* x, const float* gamma, const float
   return AWT_OK;
 }
 
-int launch_split_f32(awt_ctx* c, const float* x, int64_t n, bf16_t* hi, bf16_t* lo, hipStream_t s) {
+int launch_split_f32(awt_ctx* c, const float* x, int64_t n, float scale, bf16_t* hi, bf16_t* lo, hipStream_t s) {
   AWT_REQUIRE(x && hi && n > 0 && n % 4 == 0, AWT_ERR_INVALID, "split: n must be a positive multiple of 4");
   ProfScope prof(c, AWT_PROF_OTHER, s, 0.0);
   const int64_t n4 = n / 4;
   int grid = (int)((n4 + 255) / 256); if (grid > 4096) grid = 4096;
-  hipLaunchKernelGGL(split_kernel, dim3(grid), dim3(256), 0, s, x, n4, hi, lo);
+  hipLaunchKernelGGL(split_kernel, dim3(grid), dim3(256), 0, s, x, n4, scale, hi, lo);
   AWT_HIP_CHECK(hipGetLastError());
   return AWT_OK;
 }
