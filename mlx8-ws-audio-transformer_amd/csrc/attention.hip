@@ -13,6 +13,8 @@
 //    address; K fragments are ds_read_b128 rows, V^T fragments come from the hardware transpose read
 //    ds_read_b64_tr_b16 in the permuted key order the P operand has.
 //  * TERMS = 3 runs both products in split-bf16 (q, k, v and P as hi + lo planes, three MFMAs per fragment pair).
+//  * each wave owns QT = 2 query tiles (64 queries): K / V fragments, the LDS tile, its DMA and the barrier are amortised
+//    over 96 MFMAs instead of 48;
 //  * fp32 running max / sum / output accumulators; S = 1500 is not a multiple of 64: tail keys are masked,
 //    tail rows clamped on load and skipped on store.
 #include <type_traits>
@@ -21,8 +23,12 @@
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int QW = 32;            // queries per wave
-constexpr int QB = 128;           // queries per workgroup
+#ifndef AWT_ATTN_QT
+#define AWT_ATTN_QT 2
+#endif
+constexpr int QT = AWT_ATTN_QT;   // 32-query tiles per wave (K / V fragments, LDS tiles and the barrier are amortised over QT x 48 MFMAs)
+constexpr int QW = 32 * QT;       // queries per wave
+constexpr int QB = 4 * QW;        // queries per workgroup
 constexpr int KB = 64;            // keys per tile
 constexpr int PLANE = KB * 64 * 2;  // 8 KiB: [64 keys][64 dims] bf16
 
@@ -83,20 +89,22 @@ __global__ __launch_bounds__(kThreads, 2) void attention_kernel(AttnArgs a) {
   const int ql = lane & 31, half = lane >> 5;
 
   // ---- Q fragments (B operand of S^T = K Q^T): lane holds Q[q][16 ks + 8 half + j], j = 0..7
-  bf16x8 qh[4], qlo[4];
-  {
-    int q = q0 + ql; q = q < a.S ? q : a.S - 1;
+  bf16x8 qh[QT][4], qlo[QT][4];
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    int q = q0 + 32 * t + ql; q = q < a.S ? q : a.S - 1;
     const int64_t off = head_off + (int64_t)q * 64 + half * 8;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      qh[ks] = *reinterpret_cast<const bf16x8*>(a.q_hi + off + ks * 16);
-      if (TERMS == 3) qlo[ks] = *reinterpret_cast<const bf16x8*>(a.q_lo + off + ks * 16);
+      qh[t][ks] = *reinterpret_cast<const bf16x8*>(a.q_hi + off + ks * 16);
+      if (TERMS == 3) qlo[t][ks] = *reinterpret_cast<const bf16x8*>(a.q_lo + off + ks * 16);
     }
   }
 
-  f32x16 oacc[2];
-  oacc[0] = (f32x16){}; oacc[1] = (f32x16){};
-  float m_run = -1.0e30f, l_run = 0.f;   // running max (log2 domain) and this half-wave's partial row sum
+  f32x16 oacc[QT][2];
+  float m_run[QT], l_run[QT];            // running max (log2 domain) and this half-wave's partial row sum
+#pragma unroll
+  for (int t = 0; t < QT; ++t) { oacc[t][0] = (f32x16){}; oacc[t][1] = (f32x16){}; m_run[t] = -1.0e30f; l_run[t] = 0.f; }
 
   // ---- loop-invariant LDS byte offsets (everything else is an immediate): the swizzle term (row >> 1) & 7 does not
   // change when a row moves by 16, so sub-tiles / k-steps / dim-tiles differ by constants or by one XOR bit.
@@ -128,53 +136,61 @@ __global__ __launch_bounds__(kThreads, 2) void attention_kernel(AttnArgs a) {
     const char* v_lo = cur + 3 * PLANE;
 
     // ---- S^T = K Q^T : two 32-key sub-tiles, rows = keys, cols (lanes) = queries; q carries log2(e), so S is in log2 units
-    f32x16 sacc[2];
+    f32x16 sacc[QT][2];
 #pragma unroll
     for (int kt2 = 0; kt2 < 2; ++kt2) {
-      sacc[kt2] = (f32x16){};
+#pragma unroll
+      for (int t = 0; t < QT; ++t) sacc[t][kt2] = (f32x16){};
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const int off = koff[ks] + kt2 * 4096;
         const bf16x8 kh = *reinterpret_cast<const bf16x8*>(k_hi + off);
-        if (TERMS == 3) {
-          const bf16x8 kl = *reinterpret_cast<const bf16x8*>(k_lo + off);
-          sacc[kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qlo[ks], sacc[kt2], 0, 0, 0);
-          sacc[kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh[ks], sacc[kt2], 0, 0, 0);
+        bf16x8 kl;
+        if (TERMS == 3) kl = *reinterpret_cast<const bf16x8*>(k_lo + off);
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+          if (TERMS == 3) {
+            sacc[t][kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qlo[t][ks], sacc[t][kt2], 0, 0, 0);
+            sacc[t][kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh[t][ks], sacc[t][kt2], 0, 0, 0);
+          }
+          sacc[t][kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[t][ks], sacc[t][kt2], 0, 0, 0);
         }
-        sacc[kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[ks], sacc[kt2], 0, 0, 0);
       }
     }
 
     // ---- online softmax.  C/D layout 32x32: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 half
-    float tmax = -1.0e30f;
 #pragma unroll
-    for (int kt2 = 0; kt2 < 2; ++kt2)
+    for (int t = 0; t < QT; ++t) {
+      float tmax = -1.0e30f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        if (TAIL) {
-          const int key = kt * KB + kt2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          sacc[kt2][r] = key < a.S ? sacc[kt2][r] : -1.0e30f;
+      for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          if (TAIL) {
+            const int key = kt * KB + kt2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            sacc[t][kt2][r] = key < a.S ? sacc[t][kt2][r] : -1.0e30f;
+          }
+          tmax = fmaxf(tmax, sacc[t][kt2][r]);
         }
-        tmax = fmaxf(tmax, sacc[kt2][r]);
-      }
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-    const float m_new = fmaxf(m_run, tmax);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    m_run = m_new;
-    float psum = 0.f;
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+      const float m_new = fmaxf(m_run[t], tmax);
+      const float alpha = __builtin_amdgcn_exp2f(m_run[t] - m_new);
+      m_run[t] = m_new;
+      float psum = 0.f;
 #pragma unroll
-    for (int kt2 = 0; kt2 < 2; ++kt2)
+      for (int kt2 = 0; kt2 < 2; ++kt2)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float pv = __builtin_amdgcn_exp2f(sacc[kt2][r] - m_new);
-        sacc[kt2][r] = pv;
-        psum += pv;
-      }
-    l_run = l_run * alpha + psum;
+        for (int r = 0; r < 16; ++r) {
+          const float pv = __builtin_amdgcn_exp2f(sacc[t][kt2][r] - m_new);
+          sacc[t][kt2][r] = pv;
+          psum += pv;
+        }
+      l_run[t] = l_run[t] * alpha + psum;
 #pragma unroll
-    for (int et = 0; et < 2; ++et)
+      for (int et = 0; et < 2; ++et)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[et][r] *= alpha;
+        for (int r = 0; r < 16; ++r) oacc[t][et][r] *= alpha;
+    }
 
     // ---- O^T += V^T P^T : P registers 8 s .. 8 s + 7 of a sub-tile are the B fragment of k-step s;
     //      element j of lane-half `half` is key 16 s + 8 (j >> 2) + 4 half + (j & 3) of that sub-tile.
@@ -184,14 +200,16 @@ __global__ __launch_bounds__(kThreads, 2) void attention_kernel(AttnArgs a) {
     for (int kt2 = 0; kt2 < 2; ++kt2)
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        bf16x8 ph, pl;
+        bf16x8 ph[QT], pl[QT];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          bf16_t hi, lo;
-          split_bf16(sacc[kt2][8 * s2 + j], hi, lo);
-          ph[j] = (short)hi;
-          if (TERMS == 3) pl[j] = (short)lo;
-        }
+        for (int t = 0; t < QT; ++t)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            bf16_t hi, lo;
+            split_bf16(sacc[t][kt2][8 * s2 + j], hi, lo);
+            ph[t][j] = (short)hi;
+            if (TERMS == 3) pl[t][j] = (short)lo;
+          }
 #pragma unroll
         for (int et = 0; et < 2; ++et) {
           const int cst = kt2 * 4096 + s2 * 2048;
@@ -199,13 +217,19 @@ __global__ __launch_bounds__(kThreads, 2) void attention_kernel(AttnArgs a) {
           const int off1 = (et == 0 ? voffx : voff) + cst + 1024;
           const bf16x4 va = tr_read(v_hi + off0), vb = tr_read(v_hi + off1);
           const bf16x8 vh = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
+          bf16x8 vl;
           if (TERMS == 3) {
             const bf16x4 la = tr_read(v_lo + off0), lb = tr_read(v_lo + off1);
-            const bf16x8 vl = {la[0], la[1], la[2], la[3], lb[0], lb[1], lb[2], lb[3]};
-            oacc[et] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl, oacc[et], 0, 0, 0);
-            oacc[et] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, oacc[et], 0, 0, 0);
+            vl = (bf16x8){la[0], la[1], la[2], la[3], lb[0], lb[1], lb[2], lb[3]};
           }
-          oacc[et] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, oacc[et], 0, 0, 0);
+#pragma unroll
+          for (int t = 0; t < QT; ++t) {
+            if (TERMS == 3) {
+              oacc[t][et] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl[t], oacc[t][et], 0, 0, 0);
+              oacc[t][et] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph[t], oacc[t][et], 0, 0, 0);
+            }
+            oacc[t][et] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph[t], oacc[t][et], 0, 0, 0);
+          }
         }
       }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -215,31 +239,34 @@ __global__ __launch_bounds__(kThreads, 2) void attention_kernel(AttnArgs a) {
   if (a.S % KB) tile(std::true_type{}, ntiles - 1);
   else tile(std::false_type{}, ntiles - 1);
 
-  // ---- normalise and store: lane holds query (lane & 31), dims (r & 3) + 8 (r >> 2) + 4 half of each e-tile
-  const float l_tot = l_run + __shfl_xor(l_run, 32);
-  const float inv = 1.0f / l_tot;
-  const int q = q0 + ql;
-  if (a.lse && q < a.S && half == 0) a.lse[(int64_t)bh * a.S + q] = m_run + __builtin_amdgcn_logf(l_tot);
-  if (q < a.S) {
-    const int64_t row = ((int64_t)b * a.S + q) * (a.H * 64) + h * 64;
+  // ---- normalise and store: lane holds query (lane & 31) of each query tile, dims (r & 3) + 8 (r >> 2) + 4 half
 #pragma unroll
-    for (int et = 0; et < 2; ++et)
+  for (int t = 0; t < QT; ++t) {
+    const float l_tot = l_run[t] + __shfl_xor(l_run[t], 32);
+    const float inv = 1.0f / l_tot;
+    const int q = q0 + 32 * t + ql;
+    if (a.lse && q < a.S && half == 0) a.lse[(int64_t)bh * a.S + q] = m_run[t] + __builtin_amdgcn_logf(l_tot);
+    if (q < a.S) {
+      const int64_t row = ((int64_t)b * a.S + q) * (a.H * 64) + h * 64;
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const int e = 32 * et + 8 * g4 + 4 * half;
-        float v[4];
+      for (int et = 0; et < 2; ++et)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = oacc[et][4 * g4 + j] * inv;
-        if (a.o_f32) {
-          *reinterpret_cast<float4*>(a.o_f32 + row + e) = make_float4(v[0], v[1], v[2], v[3]);
-        } else {
-          bf16_t hi[4], lo[4];
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int e = 32 * et + 8 * g4 + 4 * half;
+          float v[4];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) split_bf16(v[j], hi[j], lo[j]);
-          *reinterpret_cast<uint2*>(a.o_hi + row + e) = make_uint2(pack2(hi[0], hi[1]), pack2(hi[2], hi[3]));
-          if (a.o_lo) *reinterpret_cast<uint2*>(a.o_lo + row + e) = make_uint2(pack2(lo[0], lo[1]), pack2(lo[2], lo[3]));
+          for (int j = 0; j < 4; ++j) v[j] = oacc[t][et][4 * g4 + j] * inv;
+          if (a.o_f32) {
+            *reinterpret_cast<float4*>(a.o_f32 + row + e) = make_float4(v[0], v[1], v[2], v[3]);
+          } else {
+            bf16_t hi[4], lo[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) split_bf16(v[j], hi[j], lo[j]);
+            *reinterpret_cast<uint2*>(a.o_hi + row + e) = make_uint2(pack2(hi[0], hi[1]), pack2(hi[2], hi[3]));
+            if (a.o_lo) *reinterpret_cast<uint2*>(a.o_lo + row + e) = make_uint2(pack2(lo[0], lo[1]), pack2(lo[2], lo[3]));
+          }
         }
-      }
+    }
   }
 }
 
