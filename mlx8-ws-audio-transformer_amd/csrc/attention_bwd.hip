@@ -14,6 +14,7 @@
 // TERMS = 3: every operand is a hi + lo bf16 pair, three MFMAs per fragment pair (DESIGN.md "Numerics").
 // Gradients are written as bf16 hi/lo planes in ROW-MAJOR [B*S, 3*d] (dq | dk | dv, dq already multiplied by the
 // head_dim^-1/2 the forward applied to q), which is the K-contiguous A operand of the QKV backward GEMM.
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -67,11 +68,11 @@ __device__ __forceinline__ void stage_tiles(const TileSrc& t1, const TileSrc& t2
 
 // acc (32 x 32, rows = tile rows in registers, cols = lanes) += T[rows] . L^T   with L fragments lane-resident
 template <int TERMS>
-__device__ __forceinline__ void rows_times_lane(f32x16& acc, const char* t_hi, const char* t_lo, int row, int half,
+__device__ __forceinline__ void rows_times_lane(f32x16& acc, const char* t_hi, const char* t_lo, const int (&roff)[4], int sub,
                                                 const bf16x8 (&lh)[4], const bf16x8 (&ll)[4]) {
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
-    const int off = row * 128 + (((2 * ks + half) ^ swz(row)) << 4);
+    const int off = roff[ks] + sub * 4096;   // the swizzle term repeats every 16 rows: the second sub-tile is a constant away
     const bf16x8 th = *reinterpret_cast<const bf16x8*>(t_hi + off);
     if (TERMS == 3) {
       const bf16x8 tl = *reinterpret_cast<const bf16x8*>(t_lo + off);
@@ -85,8 +86,7 @@ __device__ __forceinline__ void rows_times_lane(f32x16& acc, const char* t_hi, c
 // out^T (64 dims x 32 lanes, two 32-dim tiles) += T^T (transposed read of a 32-row sub-tile) . X, where X is a 32 x 32
 // accumulator tile whose registers 8 s .. 8 s + 7 form the B fragment of k-step s (cdna_hip_programming.md §3)
 template <int TERMS>
-__device__ __forceinline__ void trT_times_acc(f32x16 (&out)[2], const char* t_hi, const char* t_lo, int sub, const f32x16& x, int lane) {
-  const int g = lane >> 4, i = lane & 15, qq = i >> 2, pp = i & 3;
+__device__ __forceinline__ void trT_times_acc(f32x16 (&out)[2], const char* t_hi, const char* t_lo, int sub, const f32x16& x, int toff, int toffx) {
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     bf16x8 xh, xl;
@@ -99,12 +99,10 @@ __device__ __forceinline__ void trT_times_acc(f32x16 (&out)[2], const char* t_hi
     }
 #pragma unroll
     for (int et = 0; et < 2; ++et) {
-      const int e0 = 32 * et + 16 * (g & 1);
-      const int r0 = sub * 32 + 16 * s + 4 * (g >> 1) + qq;
-      const int chunk = (e0 >> 3) + (pp >> 1);
-      const int off0 = r0 * 128 + ((chunk ^ swz(r0)) << 4) + 8 * (pp & 1);
-      const int r1 = r0 + 8;
-      const int off1 = r1 * 128 + ((chunk ^ swz(r1)) << 4) + 8 * (pp & 1);
+      // block offsets as in attention.hip: dim-tile et toggles byte bit 6, the +8-row block adds 1024 and toggles it back
+      const int cst = sub * 4096 + s * 2048;
+      const int off0 = (et == 0 ? toff : toffx) + cst;
+      const int off1 = (et == 0 ? toffx : toff) + cst + 1024;
       const bf16x4 va = tr_read(t_hi + off0), vb = tr_read(t_hi + off1);
       const bf16x8 th = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
       if (TERMS == 3) {
@@ -182,6 +180,14 @@ __global__ __launch_bounds__(kThreads, 2) void attention_bwd_kernel(BwdArgs a) {
   f32x16 g1[2], g2[2];   // MODE_DQ: g1 = dQ^T.  MODE_DKV: g1 = dK^T, g2 = dV^T
   g1[0] = (f32x16){}; g1[1] = (f32x16){}; g2[0] = (f32x16){}; g2[1] = (f32x16){};
 
+  int roff[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) roff[ks] = ll_ * 128 + (((2 * ks + half) ^ swz(ll_)) << 4);
+  const int tg = lane >> 4, tli = lane & 15, tqq = tli >> 2, tpp = tli & 3;
+  const int trow = 4 * (tg >> 1) + tqq;
+  const int toff = trow * 128 + (((2 * (tg & 1) + (tpp >> 1)) ^ swz(trow)) << 4) + 8 * (tpp & 1);
+  const int toffx = toff ^ 64;
+
   const int ntiles = (a.S + TB - 1) / TB;
   auto stage_all = [&](int tt, char* stage) {
     stage_tiles<TERMS>(t1, t2, a.S, tt, stage, wave, lane);
@@ -195,7 +201,8 @@ __global__ __launch_bounds__(kThreads, 2) void attention_bwd_kernel(BwdArgs a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  for (int tt = 0; tt < ntiles; ++tt) {
+  auto tile = [&](auto tail_t, int tt) {
+    constexpr bool TAIL = decltype(tail_t)::value;   // only the last tile can hold streamed rows beyond S
     const char* cur = smem + (tt & 1) * STAGE;
     if (tt + 1 < ntiles) stage_all(tt + 1, smem + ((tt + 1) & 1) * STAGE);
     const char* t1_hi = cur;
@@ -203,32 +210,34 @@ __global__ __launch_bounds__(kThreads, 2) void attention_bwd_kernel(BwdArgs a) {
     const char* t2_hi = cur + (TERMS == 3 ? 2 : 1) * PLANE;
     const char* t2_lo = cur + 3 * PLANE;
     const float* stats = reinterpret_cast<const float*>(cur + NPL * PLANE);
-    const bool tail = (tt + 1) * TB > a.S;
 
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
       // s (scores) and dp for this 32-row sub-tile: rows = streamed rows (registers), cols = lanes
       f32x16 sacc = (f32x16){}, dpacc = (f32x16){};
-      rows_times_lane<TERMS>(sacc, t1_hi, t1_lo, sub * 32 + ll_, half, l1h, l1l);
-      rows_times_lane<TERMS>(dpacc, t2_hi, t2_lo, sub * 32 + ll_, half, l2h, l2l);
+      rows_times_lane<TERMS>(sacc, t1_hi, t1_lo, roff, sub, l1h, l1l);
+      rows_times_lane<TERMS>(dpacc, t2_hi, t2_lo, roff, sub, l2h, l2l);
       // MODE_DQ: s^T = K q^T (rows keys), dp^T = V dO^T.   MODE_DKV: s = Q k^T (rows queries), dp = dO v^T.
       f32x16 pacc, dsacc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int trow = sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;     // row inside the 64-row tile
+        const int trow = sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;     // row inside the 64-row tile (shadows the lane-level trow)
         const float lse = MODE == MODE_DQ ? lse_l : stats[trow];
         const float dl = MODE == MODE_DQ ? delta_l : stats[64 + trow];
         float pv = __builtin_amdgcn_exp2f(sacc[r] - lse);   // q planes carry log2(e): scores are already in log2 units
-        if (tail && tt * TB + trow >= a.S) pv = 0.f;                        // streamed row beyond S
+        if (TAIL && tt * TB + trow >= a.S) pv = 0.f;                        // streamed row beyond S
         pacc[r] = pv;
         dsacc[r] = pv * (dpacc[r] - dl);
       }
-      trT_times_acc<TERMS>(g1, t1_hi, t1_lo, sub, dsacc, lane);             // dQ^T += K^T dS^T   |  dK^T += Q^T dS
-      if (MODE == MODE_DKV) trT_times_acc<TERMS>(g2, t2_hi, t2_lo, sub, pacc, lane);   // dV^T += dO^T P
+      trT_times_acc<TERMS>(g1, t1_hi, t1_lo, sub, dsacc, toff, toffx);             // dQ^T += K^T dS^T   |  dK^T += Q^T dS
+      if (MODE == MODE_DKV) trT_times_acc<TERMS>(g2, t2_hi, t2_lo, sub, pacc, toff, toffx);   // dV^T += dO^T P
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-  }
+  };
+  for (int tt = 0; tt + 1 < ntiles; ++tt) tile(std::false_type{}, tt);
+  if (a.S % TB) tile(std::true_type{}, ntiles - 1);
+  else tile(std::false_type{}, ntiles - 1);
 
   const int row = l0 + ll_;
   if (row < a.S) {

@@ -229,40 +229,47 @@ __global__ __launch_bounds__(256) void pack_weight_t_kernel(const float* __restr
 // each thread owns 4 consecutive Y columns and r x 4 accumulators.  A second kernel sums the slabs in a fixed order,
 // so the gradients are bit-reproducible run to run.
 constexpr int kOrRows = 256;
+constexpr int kOrMaxBlocks = 128;   // workgroups walk the 256-row slabs grid-strided, so the second pass sums <= 128 partials
 template <int R>
 __global__ __launch_bounds__(256) void outer_reduce_kernel(const bf16_t* x_hi, const bf16_t* x_lo, int64_t ldx, int xcol,
                                                            const bf16_t* y_hi, const bf16_t* y_lo, int64_t ldy, int ycol, int ny, int M,
                                                            float* partial) {
   __shared__ float xs[kOrRows][R];
-  const int m0 = blockIdx.x * kOrRows;
-  const int rows = min(kOrRows, M - m0);
-  for (int i = threadIdx.x; i < rows * R; i += 256) {
-    const int mm = i / R, j = i - mm * R;
-    const int64_t o = (int64_t)(m0 + mm) * ldx + xcol + j;
-    xs[mm][j] = bf16_to_f32(x_hi[o]) + (x_lo ? bf16_to_f32(x_lo[o]) : 0.f);
-  }
-  __syncthreads();
   const int n = threadIdx.x * 4;
   float acc[R][4];
 #pragma unroll
   for (int j = 0; j < R; ++j) { acc[j][0] = acc[j][1] = acc[j][2] = acc[j][3] = 0.f; }
-  if (n < ny) {
-    for (int mm = 0; mm < rows; ++mm) {
-      const int64_t o = (int64_t)(m0 + mm) * ldy + ycol + n;
-      const uint2 yh = *reinterpret_cast<const uint2*>(y_hi + o);
-      uint2 yl = make_uint2(0u, 0u);
-      if (y_lo) yl = *reinterpret_cast<const uint2*>(y_lo + o);
-      float y[4];
-      y[0] = bf16_to_f32((bf16_t)(yh.x & 0xFFFF)) + bf16_to_f32((bf16_t)(yl.x & 0xFFFF));
-      y[1] = bf16_to_f32((bf16_t)(yh.x >> 16)) + bf16_to_f32((bf16_t)(yl.x >> 16));
-      y[2] = bf16_to_f32((bf16_t)(yh.y & 0xFFFF)) + bf16_to_f32((bf16_t)(yl.y & 0xFFFF));
-      y[3] = bf16_to_f32((bf16_t)(yh.y >> 16)) + bf16_to_f32((bf16_t)(yl.y >> 16));
+  const int nslab = (M + kOrRows - 1) / kOrRows;
+  for (int slab = blockIdx.x; slab < nslab; slab += gridDim.x) {   // fixed slab -> workgroup map: the sum order is reproducible
+    const int m0 = slab * kOrRows;
+    const int rows = min(kOrRows, M - m0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < rows * R; i += 256) {
+      const int mm = i / R, j = i - mm * R;
+      const int64_t o = (int64_t)(m0 + mm) * ldx + xcol + j;
+      xs[mm][j] = bf16_to_f32(x_hi[o]) + (x_lo ? bf16_to_f32(x_lo[o]) : 0.f);
+    }
+    __syncthreads();
+    if (n < ny) {
+      for (int mm = 0; mm < rows; ++mm) {
+        const int64_t o = (int64_t)(m0 + mm) * ldy + ycol + n;
+        const uint2 yh = *reinterpret_cast<const uint2*>(y_hi + o);
+        uint2 yl = make_uint2(0u, 0u);
+        if (y_lo) yl = *reinterpret_cast<const uint2*>(y_lo + o);
+        float y[4];
+        y[0] = bf16_to_f32((bf16_t)(yh.x & 0xFFFF)) + bf16_to_f32((bf16_t)(yl.x & 0xFFFF));
+        y[1] = bf16_to_f32((bf16_t)(yh.x >> 16)) + bf16_to_f32((bf16_t)(yl.x >> 16));
+        y[2] = bf16_to_f32((bf16_t)(yh.y & 0xFFFF)) + bf16_to_f32((bf16_t)(yl.y & 0xFFFF));
+        y[3] = bf16_to_f32((bf16_t)(yh.y >> 16)) + bf16_to_f32((bf16_t)(yl.y >> 16));
 #pragma unroll
-      for (int j = 0; j < R; ++j) {
-        const float xv = xs[mm][j];
-        acc[j][0] += xv * y[0]; acc[j][1] += xv * y[1]; acc[j][2] += xv * y[2]; acc[j][3] += xv * y[3];
+        for (int j = 0; j < R; ++j) {
+          const float xv = xs[mm][j];
+          acc[j][0] += xv * y[0]; acc[j][1] += xv * y[1]; acc[j][2] += xv * y[2]; acc[j][3] += xv * y[3];
+        }
       }
     }
+  }
+  if (n < ny) {
     float* p = partial + (int64_t)blockIdx.x * R * ny;
 #pragma unroll
     for (int j = 0; j < R; ++j) *reinterpret_cast<float4*>(p + (int64_t)j * ny + n) = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
@@ -340,7 +347,8 @@ int launch_pack_weight_t(awt_ctx* c, const float* src, int N, int C, int64_t ld,
 
 size_t outer_reduce_partial_bytes(int M, int r, int ny) {
   const int R = r <= 8 ? 8 : (r <= 16 ? 16 : 32);
-  return (size_t)((M + kOrRows - 1) / kOrRows) * R * ny * sizeof(float);
+  const int nslab = (M + kOrRows - 1) / kOrRows;
+  return (size_t)(nslab < kOrMaxBlocks ? nslab : kOrMaxBlocks) * R * ny * sizeof(float);
 }
 
 int launch_outer_reduce(awt_ctx* c, const bf16_t* x_hi, const bf16_t* x_lo, int64_t ldx, int xcol, int r, const bf16_t* y_hi,
@@ -350,7 +358,8 @@ int launch_outer_reduce(awt_ctx* c, const bf16_t* x_hi, const bf16_t* x_lo, int6
   AWT_REQUIRE(ldy % 4 == 0 && ycol % 4 == 0, AWT_ERR_INVALID, "outer_reduce: Y columns must be 8-byte aligned");
   AWT_REQUIRE(partial_bytes >= outer_reduce_partial_bytes(M, r, ny), AWT_ERR_WORKSPACE, "outer_reduce: partial buffer too small");
   ProfScope prof(c, AWT_PROF_OTHER, s, 0.0);
-  const int nslab = (M + kOrRows - 1) / kOrRows;
+  const int nslab_all = (M + kOrRows - 1) / kOrRows;
+  const int nslab = nslab_all < kOrMaxBlocks ? nslab_all : kOrMaxBlocks;   // = workgroups = partial sums
   const int R = r <= 8 ? 8 : (r <= 16 ? 16 : 32);
   // X columns beyond r inside the R-wide register block read neighbouring (valid, in-row) columns and are discarded below
   AWT_REQUIRE(xcol + R <= ldx, AWT_ERR_INVALID, "outer_reduce: X block exceeds its row");
