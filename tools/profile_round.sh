@@ -9,6 +9,38 @@ timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/t
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc_$c -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-fast-mode > $out/pmc_$c.log 2>&1
 done
+# MFMA utilisation and effective clock (own pass; SQ + GRBM slots)
+timeout -k 10 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_MFMA -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-fast-mode > $out/pmc_MFMA.log 2>&1
+python3 - $out $tag <<'PY2'
+import csv, glob, json, sys, collections
+out, tag = sys.argv[1], sys.argv[2]
+def short(n):
+    for k in ("gemm_kernel", "attention_kernel", "layernorm_kernel", "logmel_stage1", "logmel_finalize", "im2col"):
+        if k in n: return k
+cc = glob.glob(f"{out}/pmc_MFMA/**/*counter_collection.csv", recursive=True)
+kt = glob.glob(f"{out}/pmc_MFMA/**/*kernel_trace.csv", recursive=True)
+if cc and kt:
+    dur = {r["Dispatch_Id"]: int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(kt[0]))}
+    acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter(); t = collections.Counter(); seen = set()
+    for r in csv.DictReader(open(cc[0])):
+        k = short(r["Kernel_Name"])
+        if not k: continue
+        acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        if r["Dispatch_Id"] not in seen:
+            seen.add(r["Dispatch_Id"]); n[k] += 1; t[k] += dur.get(r["Dispatch_Id"], 0)
+    res = {}
+    for k, d in acc.items():
+        cyc = d["GRBM_GUI_ACTIVE"] / 8.0                      # summed over the 8 XCDs
+        res[k] = {"launches_counted": n[k], "avg_ns": t[k] / max(n[k], 1),
+                  "effective_clock_ghz": cyc / max(t[k], 1),
+                  "mfma_busy_frac": d["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * cyc) if cyc else None,   # 1024 SIMDs
+                  "wave_cycles_wait_any_frac": d["SQ_WAIT_ANY"] / d["SQ_WAVE_CYCLES"] if d["SQ_WAVE_CYCLES"] else None,
+                  "wave_cycles_wait_inst_frac": d["SQ_WAIT_INST_ANY"] / d["SQ_WAVE_CYCLES"] if d["SQ_WAVE_CYCLES"] else None,
+                  "wave_cycles_active_frac": d["SQ_ACTIVE_INST_ANY"] / d["SQ_WAVE_CYCLES"] if d["SQ_WAVE_CYCLES"] else None}
+    json.dump({"tag": tag, "note": "profiled pass (clocks read ~2-3 % lower than un-profiled); mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)",
+               "per_kernel": res}, open(f"{out}/mfma.json", "w"), indent=1)
+    print(json.dumps(res, indent=1))
+PY2
 python3 - $out $tag <<'PY'
 import csv, glob, json, sys, collections
 out, tag = sys.argv[1], sys.argv[2]
