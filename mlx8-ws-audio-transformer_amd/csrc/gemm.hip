@@ -146,11 +146,35 @@ struct Stager {
 };
 
 // Epilogue on four consecutive columns of one row (the accumulators are transposed through LDS first, so a lane owns
-// a 16-byte fp32 / 8-byte bf16 piece of a row and 16 lanes cover 64 contiguous columns).
+// a 16-byte fp32 / 8-byte bf16 piece of a row and 16 lanes cover 64 contiguous columns).  Side inputs (residual row,
+// positional table, saved pre-activation) are loaded by load_side4 one strip AHEAD of their use: in the epilogue every
+// wave of the workgroup is past its last MFMA, so a load-then-use per strip would expose its latency eight times.
 template <int EPI>
-__device__ __forceinline__ void store_out4(const GemmOut& o, int m, int n, float4 acc, int M) {
+__device__ __forceinline__ float4 load_side4(const GemmOut& o, int m, int n, int M) {
+  float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (m >= M || n >= o.n_valid) return r;
+  if (EPI == EPI_F32_RESID) {
+    r = *reinterpret_cast<const float4*>(o.resid + (int64_t)m * o.ldo + n);
+  } else if (EPI == EPI_F32_GELU_POS) {
+    r = *reinterpret_cast<const float4*>(o.pos + (int64_t)(m % o.rows_pos) * o.ldo + n);
+  } else if (EPI == EPI_BF16_DGELU) {
+    const int64_t off = (int64_t)m * o.ldo + n;
+    const uint2 ph = *reinterpret_cast<const uint2*>(o.pre_hi + off);
+    uint2 pl = make_uint2(0u, 0u);
+    if (o.pre_lo) pl = *reinterpret_cast<const uint2*>(o.pre_lo + off);
+    r.x = bf16_to_f32((bf16_t)(ph.x & 0xFFFF)) + bf16_to_f32((bf16_t)(pl.x & 0xFFFF));
+    r.y = bf16_to_f32((bf16_t)(ph.x >> 16)) + bf16_to_f32((bf16_t)(pl.x >> 16));
+    r.z = bf16_to_f32((bf16_t)(ph.y & 0xFFFF)) + bf16_to_f32((bf16_t)(pl.y & 0xFFFF));
+    r.w = bf16_to_f32((bf16_t)(ph.y >> 16)) + bf16_to_f32((bf16_t)(pl.y >> 16));
+  }
+  return r;
+}
+
+template <int EPI>
+__device__ __forceinline__ void store_out4(const GemmOut& o, int m, int n, float4 acc, float4 side, int M) {
   if (m >= M || n >= o.n_valid) return;
   float v[4] = {acc.x, acc.y, acc.z, acc.w};
+  const float sd[4] = {side.x, side.y, side.z, side.w};
   if (o.bias) {
     const float4 b = *reinterpret_cast<const float4*>(o.bias + n);
     v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
@@ -158,11 +182,11 @@ __device__ __forceinline__ void store_out4(const GemmOut& o, int m, int n, float
   if (EPI == EPI_F32 || EPI == EPI_F32_RESID || EPI == EPI_F32_GELU_POS) {
     float* dst = o.f32 + (int64_t)m * o.ldo + n;
     if (EPI == EPI_F32_RESID) {
-      const float4 r = *reinterpret_cast<const float4*>(o.resid + (int64_t)m * o.ldo + n);
-      v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) v[t] += sd[t];
     } else if (EPI == EPI_F32_GELU_POS) {
-      const float4 ps = *reinterpret_cast<const float4*>(o.pos + (int64_t)(m % o.rows_pos) * o.ldo + n);
-      v[0] = gelu_erf(v[0]) + ps.x; v[1] = gelu_erf(v[1]) + ps.y; v[2] = gelu_erf(v[2]) + ps.z; v[3] = gelu_erf(v[3]) + ps.w;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) v[t] = gelu_erf(v[t]) + sd[t];
     }
     *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
   } else {
@@ -184,15 +208,10 @@ __device__ __forceinline__ void store_out4(const GemmOut& o, int m, int n, float
         if (o.lo2) *reinterpret_cast<uint2*>(o.lo2 + off) = make_uint2(pack2(pl[0], pl[1]), pack2(pl[2], pl[3]));
       }
       if (EPI == EPI_BF16_DGELU) {
-        const uint2 ph = *reinterpret_cast<const uint2*>(o.pre_hi + off);
-        uint2 pl = make_uint2(0u, 0u);
-        if (o.pre_lo) pl = *reinterpret_cast<const uint2*>(o.pre_lo + off);
-        const unsigned hw[2] = {ph.x, ph.y}, lw[2] = {pl.x, pl.y};
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          const float x = bf16_to_f32((bf16_t)(hw[t >> 1] >> (16 * (t & 1)))) + bf16_to_f32((bf16_t)(lw[t >> 1] >> (16 * (t & 1))));
-          // d/dx gelu(x) = Phi(x) + x phi(x)
-          v[t] *= 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+          const float x = sd[t];   // d/dx gelu(x) = Phi(x) + x phi(x)
+          v[t] *= 0.5f * (1.0f + erf_fast(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
         }
       } else {
 #pragma unroll
@@ -412,20 +431,30 @@ __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, 2) void gemm_kernel(GemmArg
   static_assert(TN == 4, "epilogue strips are 64 columns wide");
   constexpr int PITCH = 68;  // floats; 16 x 68 x 4 B = 4352 B per wave
   float* patch = reinterpret_cast<float*>(smem) + wave * (16 * PITCH);
+  const int em0 = m0 + wr * TM * 16, en = n0 + wc * 64 + frow * 4;
+  float4 side[4], side_next[4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) side[it] = load_side4<EPI>(g.out, em0 + fq + 4 * it, en, g.M);
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) patch[(fq * 4 + rr) * PITCH + j * 16 + frow] = acc[i][j][rr];
+    if (i + 1 < TM) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) side_next[it] = load_side4<EPI>(g.out, em0 + (i + 1) * 16 + fq + 4 * it, en, g.M);
+    }
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
-      const int rl = fq + 4 * it, cl = frow * 4;
-      const float4 v = *reinterpret_cast<const float4*>(patch + rl * PITCH + cl);
-      store_out4<EPI>(g.out, m0 + (wr * TM + i) * 16 + rl, n0 + wc * 64 + cl, v, g.M);
+      const int rl = fq + 4 * it;
+      const float4 v = *reinterpret_cast<const float4*>(patch + rl * PITCH + frow * 4);
+      store_out4<EPI>(g.out, em0 + i * 16 + rl, en, v, side[it], g.M);
     }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) side[it] = side_next[it];
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
