@@ -26,6 +26,7 @@ constexpr int kMaxSeg = 3;
 
 struct GemmArgs {
   int M, N, nseg, tiles_m, tiles_n;
+  int m_begin;           // first output row of this launch (a GEMM may be split into a main launch and a finer-tiled tail)
   GemmSeg seg[kMaxSeg];
   GemmOut out;
   const bf16_t* zeros;   // >= 128 zero bytes (padding rows of the conv stem)
@@ -34,6 +35,7 @@ struct GemmArgs {
 // block-tile configurations: WM x WN waves, each wave TM x TN tiles of 16 x 16
 struct Cfg128 { static constexpr int WM = 2, WN = 2, TM = 4, TN = 4; };
 struct Cfg256 { static constexpr int WM = 2, WN = 4, TM = 8, TN = 4; };
+struct Cfg128x256 { static constexpr int WM = 2, WN = 4, TM = 4, TN = 4; };   // half-height tiles for the last, partial round
 
 template <int BK> __device__ __forceinline__ int swz(int row);
 // BK = 64: 128-byte rows, 8 chunks of 16 B; BK = 32: 64-byte rows, 4 chunks.  See DESIGN.md "LDS images".
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, 2) void gemm_kernel(GemmArg
   const int q = nwg >> 3, r = nwg & 7;
   const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
-  const int m0 = tm * T::BM, n0 = tn * T::BN;
+  const int m0 = g.m_begin + tm * T::BM, n0 = tn * T::BN;
 
   int ktiles = 0;
   for (int s = 0; s < g.nseg; ++s) ktiles += g.seg[s].K / BK;
@@ -468,7 +470,7 @@ int launch_one(GemmArgs a, hipStream_t s) {
     AWT_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_kernel<TERMS, BK, EPI, CFG>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * T::STAGE));
     attr = true;
   }
-  a.tiles_m = (a.M + T::BM - 1) / T::BM;
+  a.tiles_m = (a.M - a.m_begin + T::BM - 1) / T::BM;
   a.tiles_n = (a.N + T::BN - 1) / T::BN;
   hipLaunchKernelGGL((gemm_kernel<TERMS, BK, EPI, CFG>), dim3(a.tiles_m * a.tiles_n), dim3(T::THREADS), 2 * T::STAGE, s, a);
   AWT_HIP_CHECK(hipGetLastError());
@@ -477,11 +479,31 @@ int launch_one(GemmArgs a, hipStream_t s) {
 
 int g_force_tile = 0;  // 0 = auto, 128 / 256 = forced (tuning and tests)
 
+// 256 x 256 tiles on 256 CUs: a launch is ceil(tiles / 256) rounds long, and the encoder's shapes leave the last round
+// 18 - 58 % full (N = 768: 1125 tiles = 4.39 rounds -> 5).  When it pays, the rows of the partial round are computed
+// by a second launch with 128 x 256 tiles, which spreads them over twice as many CUs for half as long.
+constexpr int kCUs = 256;
 template <int EPI>
-int launch_epi(const GemmArgs& a, int terms, hipStream_t s) {
+int launch_epi(GemmArgs a, int terms, hipStream_t s) {
   const bool big = g_force_tile ? g_force_tile == 256 : (a.N % 256 == 0 && a.M >= 2048);
-  if (big) return terms == 3 ? launch_one<3, 32, EPI, Cfg256>(a, s) : launch_one<1, 64, EPI, Cfg256>(a, s);
-  return terms == 3 ? launch_one<3, 32, EPI, Cfg128>(a, s) : launch_one<1, 64, EPI, Cfg128>(a, s);
+  a.m_begin = 0;
+  if (!big) return terms == 3 ? launch_one<3, 32, EPI, Cfg128>(a, s) : launch_one<1, 64, EPI, Cfg128>(a, s);
+  const int tn = a.N / 256, tm = (a.M + 255) / 256, tiles = tm * tn;
+  const int full_rounds = tiles / kCUs;
+  const int tm_main = full_rounds * kCUs / tn;                 // row panels whose tiles fill whole rounds
+  const int rows_left = a.M - tm_main * 256;
+  const int tail_tiles = ((rows_left + 127) / 128) * tn;
+  // rounds (in units of a 256 x 256 tile's duration): one launch vs main + half-height tail
+  const double one = (double)((tiles + kCUs - 1) / kCUs);
+  const double split = (double)((tm_main * tn + kCUs - 1) / kCUs) + 0.5 * (double)((tail_tiles + kCUs - 1) / kCUs) + 0.05;
+  if (full_rounds >= 1 && rows_left > 0 && split < one) {
+    GemmArgs m = a; m.M = tm_main * 256;
+    int rc = terms == 3 ? launch_one<3, 32, EPI, Cfg256>(m, s) : launch_one<1, 64, EPI, Cfg256>(m, s);
+    if (rc) return rc;
+    GemmArgs t = a; t.m_begin = tm_main * 256;
+    return terms == 3 ? launch_one<3, 32, EPI, Cfg128x256>(t, s) : launch_one<1, 64, EPI, Cfg128x256>(t, s);
+  }
+  return terms == 3 ? launch_one<3, 32, EPI, Cfg256>(a, s) : launch_one<1, 64, EPI, Cfg256>(a, s);
 }
 
 bf16_t* g_zeros = nullptr;
