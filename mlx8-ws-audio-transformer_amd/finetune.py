@@ -95,8 +95,11 @@ class WhisperLoRAModel(nn.Module):
     (HF:modeling_whisper.py:994-1100): shift labels right, encoder, decoder, tied projection, CE with ignore -100."""
 
     def __init__(self, cfg: EncoderConfig, lora: LoraSpec, precision: str = "bf16x3", device: str = "cuda", decoder_layers: Optional[int] = None,
-                 seed: int = 0, vocab: int = WHISPER_VOCAB):
+                 seed: int = 0, vocab: int = WHISPER_VOCAB, decoder_autocast: Optional[torch.dtype] = None):
         super().__init__()
+        # the decoder is stock PyTorch (scope row "next"): fp32 like the reference (fp16=False, fineTune.py:170) unless
+        # decoder_autocast=torch.bfloat16 asks torch to run its matmuls in bf16
+        self.decoder_autocast = decoder_autocast
         self.encoder = NativeWhisperEncoder(cfg, precision=precision, lora=lora, device=device, seed=seed, trainable=True)
         torch.manual_seed(seed)
         self.decoder = WhisperDecoder(cfg.d_model, decoder_layers or cfg.layers, cfg.heads, cfg.ffn, vocab).to(device)
@@ -113,7 +116,8 @@ class WhisperLoRAModel(nn.Module):
                 raise ValueError("either labels or decoder_input_ids is required")
             decoder_input_ids = shift_tokens_right(labels, self.config.pad_token_id, self.config.decoder_start_token_id)
         hidden = self.encoder(input_features).last_hidden_state
-        logits = self.decoder(decoder_input_ids.to(hidden.device), hidden)
+        with torch.autocast("cuda", dtype=self.decoder_autocast or torch.bfloat16, enabled=self.decoder_autocast is not None):
+            logits = self.decoder(decoder_input_ids.to(hidden.device), hidden)
         loss = None
         if labels is not None:
             loss = F.cross_entropy(logits.view(-1, logits.shape[-1]).float(), labels.to(hidden.device).reshape(-1), ignore_index=-100)
