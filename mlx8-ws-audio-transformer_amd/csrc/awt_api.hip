@@ -208,7 +208,7 @@ Workspace carve(const awt_encoder* e, char* base, int Bc) {
 GemmSeg seg_plain(const bf16_t* a_hi, const bf16_t* a_lo, int64_t lda, const Planes& w, int64_t wcol, int K, int M) {
   GemmSeg s{};
   s.a_hi = a_hi; s.a_lo = a_lo; s.lda = lda;
-  s.w_hi = w.hi + wcol; s.w_lo = w.lo ? w.lo + wcol : nullptr; s.ldw = w.ld; s.K = K;
+  s.w_hi = w.hi; s.w_lo = w.lo; s.w_ksteps = (int)(w.ld / 32); s.w_k0 = (int)(wcol / 32); s.K = K;
   s.rows_out = M; s.rows_in = M; s.row_mul = 1; s.row_add = 0;
   return s;
 }
@@ -595,9 +595,9 @@ extern "C" int awt_op_linear(awt_ctx* c, const float* x, const float* w, const f
   bf16_t* wh = (bf16_t*)base;                 base += align_up((size_t)N * K * 2);
   bf16_t* wl = (bf16_t*)base;
   int rc = launch_split_f32(c, x, (int64_t)M * K, 1.0f, xh, xl, s); if (rc) return rc;
-  rc = launch_split_f32(c, w, (int64_t)N * K, 1.0f, wh, wl, s); if (rc) return rc;
+  rc = launch_pack_weight(c, w, N, K, 1, K, 0, 0, 1.0f, wh, wl, s); if (rc) return rc;     // fragment-major
   GemmSeg sg{};
-  sg.a_hi = xh; sg.a_lo = xl; sg.lda = K; sg.w_hi = wh; sg.w_lo = wl; sg.ldw = K; sg.K = K;
+  sg.a_hi = xh; sg.a_lo = xl; sg.lda = K; sg.w_hi = wh; sg.w_lo = wl; sg.w_ksteps = K / 32; sg.w_k0 = 0; sg.K = K;
   sg.rows_out = M; sg.rows_in = M; sg.row_mul = 1; sg.row_add = 0;
   GemmOut o{}; o.f32 = y; o.ldo = N; o.bias = bias; o.n_valid = N;
   return launch_gemm(c, M, N, &sg, 1, terms, EPI_F32, o, s);

@@ -46,6 +46,16 @@ __device__ __forceinline__ float erf_fast(float x) {
 // erf GELU (not the tanh form), as torch.nn.functional.gelu (HF:modeling_whisper.py:618-619, activation_function "gelu")
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f)); }
 
+// Fragment-major weight layout.  Every "W-side" GEMM operand is library-owned and static within a step, so it is stored
+// the way v_mfma_f32_16x16x32_bf16 consumes it: for each (16-row n-tile, 32-wide k-step) one contiguous 1 KB block holding
+// lane l's B fragment W[16 nt + (l & 15)][32 ks + 8 (l >> 4) + 0..7] at bytes 16 l .. 16 l + 15.  A wave then fetches a
+// fragment with ONE fully coalesced 16-byte-per-lane global load straight into registers -- the weights never touch LDS
+// or the LDS-DMA path, which is the GEMM's bottleneck.
+__host__ __device__ __forceinline__ int64_t w_frag_index(int n, int k, int ksteps) {
+  const int nt = n >> 4, r = n & 15, ks = k >> 5, kq = (k & 31) >> 3, j = k & 7;
+  return (((int64_t)nt * ksteps + ks) * 64 + (kq * 16 + r)) * 8 + j;
+}
+
 // ---------------------------------------------------------------- host-side error plumbing
 void awt_set_error(const std::string& msg);
 int awt_fail(int code, const std::string& msg);
@@ -88,7 +98,9 @@ struct ProfScope {
 // GEMM:  C[M, N] = sum_seg A_seg[rowmap(m), 0:K_seg] . W_seg[n, 0:K_seg]^T, operands bf16 hi (+ lo when terms == 3)
 struct GemmSeg {
   const bf16_t* a_hi; const bf16_t* a_lo; int64_t lda;   // activations, K contiguous
-  const bf16_t* w_hi; const bf16_t* w_lo; int64_t ldw;   // weights [N, K_seg], K contiguous
+  // weights in FRAGMENT-MAJOR order (w_frag_index below): element (n, k) of a matrix with `w_ksteps` = K_total / 32
+  // k-steps; the segment starts at k-step `w_k0` of that matrix
+  const bf16_t* w_hi; const bf16_t* w_lo; int w_ksteps, w_k0;
   int K;                                                 // multiple of the kernel's BK
   // source row of output row m:  (m / rows_out) * rows_in + (m % rows_out) * row_mul + row_add ; rows outside
   // [0, rows_in) of their group read as zeros (the conv stem's padding).  Plain GEMM: rows_out = rows_in = M.
@@ -129,7 +141,8 @@ int launch_attention(awt_ctx* c, const bf16_t* q_hi, const bf16_t* q_lo, const b
                      const bf16_t* v_hi, const bf16_t* v_lo, bf16_t* o_hi, bf16_t* o_lo, float* o_f32, float* lse, int B, int H,
                      int S, int terms, hipStream_t s);
 int launch_split_f32(awt_ctx* c, const float* x, int64_t n, float scale, bf16_t* hi, bf16_t* lo, hipStream_t s);
-// weights: dst[(row_off + n) * ld + col_off + k] = scale * src[n, c, dt], k = dt * C + c (taps = 1: plain [N, C])
+// weights: dst(row_off + n, col_off + k) = scale * src[n, c, dt], k = dt * C + c (taps = 1: plain [N, C]); dst is a
+// fragment-major matrix with ld / 32 k-steps (ld = its K, a multiple of 32; its row count a multiple of 16)
 int launch_pack_weight(awt_ctx* c, const float* src, int N, int C, int taps, int64_t ld, int row_off, int col_off, float scale,
                        bf16_t* hi, bf16_t* lo, hipStream_t s);
 // conv1 im2col: mel f32 [B, C, T] -> A [B*T, K_dst] bf16 hi/lo, k = dt * C + c reads mel[b, c, t + dt - 1]
@@ -150,7 +163,7 @@ int launch_attention_bwd(awt_ctx* c, const bf16_t* q_hi, const bf16_t* q_lo, con
 // dx = dres + LayerNorm_backward(dy; x, gamma)  (fp32), plus bf16 hi/lo planes of dx for the next GEMM; dres may be null
 int launch_layernorm_bwd(awt_ctx* c, const float* dy, const float* x, const float* gamma, const float* dres, int M, int d, float eps,
                          float* dx, bf16_t* dx_hi, bf16_t* dx_lo, hipStream_t s);
-// dst[(row_off + c) * ld + col_off + n] = scale * src[n, c]   (transposed copy of an [N, C] fp32 matrix into bf16 planes)
+// dst(row_off + c, col_off + n) = scale * src[n, c]   (transposed copy of an [N, C] fp32 matrix into fragment-major planes)
 int launch_pack_weight_t(awt_ctx* c, const float* src, int N, int C, int64_t ld, int row_off, int col_off, float scale, bf16_t* hi,
                          bf16_t* lo, hipStream_t s);
 // out[j * sj + n * sn] = scale * sum_m X[m, xcol + j] * Y[m, ycol + n]   for j < r, n < ny  (LoRA dA / dB; fp32 result)

@@ -73,9 +73,10 @@ __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ x,
 }
 
 // ------------------------------------------------------------------------------------------------ weight packing
-// dst[(row_off + n) * ld + col_off + k] = src[n, c, dt] * scale with k = dt * C + c  (conv weights [N, C, taps] ->
-// K-contiguous implicit-GEMM rows; taps = 1 is a plain [N, C] linear weight).  Only the N x (C * taps) region is
-// written: destination buffers are zero-initialised at creation, which provides every padding row / column.
+// dst(row_off + n, col_off + k) = src[n, c, dt] * scale with k = dt * C + c  (conv weights [N, C, taps] -> implicit-GEMM
+// rows; taps = 1 is a plain [N, C] linear weight), written in the fragment-major layout of w_frag_index().  Only the
+// N x (C * taps) region is written: destination buffers are zero-initialised at creation, which provides every padding
+// row / column.
 __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ src, int N, int C, int taps, int64_t ld,
                                                           int row_off, int col_off, float scale, bf16_t* hi, bf16_t* lo) {
   const int K = C * taps;
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
     const int dt = k / C, c = k - dt * C;
     const float v = src[((int64_t)n * C + c) * taps + dt] * scale;
     bf16_t h, l; split_bf16(v, h, l);
-    const int64_t o = (int64_t)(row_off + n) * ld + col_off + k;
+    const int64_t o = w_frag_index(row_off + n, col_off + k, (int)(ld >> 5));
     hi[o] = h;
     if (lo) lo[o] = l;
   }
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(256) void pack_weight_t_kernel(const float* __restr
     const int c = c0 + r, n = n0 + tx;
     if (c < C && n < N) {
       bf16_t h, l; split_bf16(tile[tx][r] * scale, h, l);
-      const int64_t o = (int64_t)(row_off + c) * ld + col_off + n;
+      const int64_t o = w_frag_index(row_off + c, col_off + n, (int)(ld >> 5));
       hi[o] = h;
       if (lo) lo[o] = l;
     }
@@ -310,7 +311,7 @@ int launch_split_f32(awt_ctx* c, const float* x, int64_t n, float scale, bf16_t*
 
 int launch_pack_weight(awt_ctx* c, const float* src, int N, int C, int taps, int64_t ld, int row_off, int col_off, float scale,
                        bf16_t* hi, bf16_t* lo, hipStream_t s) {
-  AWT_REQUIRE(src && hi && N > 0 && C > 0 && taps > 0 && ld >= col_off + (int64_t)C * taps, AWT_ERR_INVALID, "pack_weight: bad shape");
+  AWT_REQUIRE(src && hi && N > 0 && C > 0 && taps > 0 && ld >= col_off + (int64_t)C * taps && ld % 32 == 0, AWT_ERR_INVALID, "pack_weight: bad shape");
   const int64_t total = (int64_t)N * C * taps;
   int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
   hipLaunchKernelGGL(pack_weight_kernel, dim3(grid), dim3(256), 0, s, src, N, C, taps, ld, row_off, col_off, scale, hi, lo);
@@ -339,7 +340,7 @@ int launch_layernorm_bwd(awt_ctx* c, const float* dy, const float* x, const floa
 
 int launch_pack_weight_t(awt_ctx* c, const float* src, int N, int C, int64_t ld, int row_off, int col_off, float scale, bf16_t* hi,
                          bf16_t* lo, hipStream_t s) {
-  AWT_REQUIRE(src && hi && N > 0 && C > 0 && ld >= col_off + N, AWT_ERR_INVALID, "pack_weight_t: bad shape");
+  AWT_REQUIRE(src && hi && N > 0 && C > 0 && ld >= col_off + N && ld % 32 == 0, AWT_ERR_INVALID, "pack_weight_t: bad shape");
   hipLaunchKernelGGL(pack_weight_t_kernel, dim3((N + 31) / 32, (C + 31) / 32), dim3(256), 0, s, src, N, C, ld, row_off, col_off, scale, hi, lo);
   AWT_HIP_CHECK(hipGetLastError());
   return AWT_OK;

@@ -1,6 +1,6 @@
-// bf16 MFMA GEMM with fused epilogues for the encoder's dense contractions (K5, K6, K9, K11, K12, K13) -- gfx950.
+// bf16 MFMA GEMM with fused epilogues for the encoder's dense contractions (K5, K6, K9, K11, K12, K13, K14) -- gfx950.
 //
-//   C[M, N] = sum over K-segments  A_seg[rowmap(m), :] . W_seg[n, :]^T       (both operands K-contiguous)
+//   C[M, N] = sum over K-segments  A_seg[rowmap(m), :] . W_seg[n, :]^T
 //
 // * operands are bf16 "hi" planes, optionally with "lo" planes (x = hi + lo, |x - hi - lo| <= 2^-17 |x|).
 //   TERMS = 1: acc += a_hi b_hi.  TERMS = 3: acc += a_hi b_lo + a_lo b_hi + a_hi b_hi  (split-bf16: the mode
@@ -8,15 +8,22 @@
 // * K-segments let one kernel serve: plain linears (1 segment), linears with a LoRA term
 //   ([x | u] . [W | B]^T, 2 segments) and the stride-2 conv stem as an implicit GEMM (3 taps = 3 segments whose
 //   source row is 2 s + tap - 1, rows outside the clip reading as zero).
-// * two block tiles: 256 x 256 (8 waves as 2 x 4, each 128 x 64 = 8 x 4 tiles of v_mfma_f32_16x16x32_bf16; one
-//   workgroup per CU, 128 KiB LDS) for the large-N encoder shapes -- at 128 x 128 the L2 -> LDS traffic per MFMA
-//   FLOP is twice as high and the kernel sits on the L2 bandwidth instead of the matrix pipe -- and 128 x 128
-//   (4 waves as 2 x 2) for N not a multiple of 256.
-//   Tiles are staged global -> LDS with 16-byte LDS-DMA (global_load_lds_dwordx4), double buffered, one barrier per
-//   K-tile; LDS rows are XOR-swizzled on the SOURCE address (the DMA writes LDS linearly) and on the ds_read_b128,
-//   so fragment reads are bank-conflict free.
-// * 1-D grid with an XCD-aware remap: consecutive tiles of one A row-panel run on one XCD so the panel is fetched
-//   from HBM once and then served by that XCD's L2.
+// * block tiles: 256 x 256 (8 waves as 2 x 4, each 128 x 64 = 8 x 4 tiles of v_mfma_f32_16x16x32_bf16; one workgroup
+//   per CU) for the large encoder shapes, 128 x 256 for the rows of a launch's last partial round, 128 x 128 (4 waves)
+//   for N not a multiple of 256.
+// * the two operands take DIFFERENT routes on purpose.  The per-CU global -> LDS DMA path tops out near 13 B/clk
+//   (measured: every variant of an all-LDS kernel ran at 22 - 30 GB/s of DMA per CU, and 64 KB of tiles per K-step of
+//   3072 MFMA cycles needs 21 B/clk).  So only the ACTIVATION tile goes through LDS (16-byte LDS-DMA, double buffered,
+//   rows XOR-swizzled on the source address and on the ds_read_b128); the WEIGHT fragments are read straight into
+//   registers from a fragment-major copy of the weights (w_frag_index in common.h: one coalesced 1 KB block per
+//   fragment), one K-tile ahead.  That halves the DMA bytes, removes a third of the LDS reads and leaves the LDS
+//   ring at 64 KB.
+// * K loop: a K-tile is (BK / 32) x TM steps of TN x TERMS MFMAs; the A fragments of the next step are read from LDS,
+//   and one or two of the next K-tile's memory operations (A DMA pieces, W fragment loads) are issued, before each
+//   step's MFMAs; one barrier per K-tile.
+// * 1-D grid with an XCD-aware remap: consecutive tiles of one A row-panel run on one XCD.
+// * epilogue: accumulators are transposed through a per-wave LDS patch so every store is a whole 128 - 256 B row
+//   segment; side inputs are prefetched one strip ahead.
 #include <type_traits>
 #include "common.h"
 
@@ -26,7 +33,6 @@ constexpr int kMaxSeg = 3;
 
 struct GemmArgs {
   int M, N, nseg, tiles_m, tiles_n;
-  int m_begin;           // first output row of this launch (a GEMM may be split into a main launch and a finer-tiled tail)
   GemmSeg seg[kMaxSeg];
   GemmOut out;
   const bf16_t* zeros;   // >= 128 zero bytes (padding rows of the conv stem)
@@ -34,8 +40,7 @@ struct GemmArgs {
 
 // block-tile configurations: WM x WN waves, each wave TM x TN tiles of 16 x 16
 struct Cfg128 { static constexpr int WM = 2, WN = 2, TM = 4, TN = 4; };
-struct Cfg256 { static constexpr int WM = 2, WN = 4, TM = 8, TN = 4; };
-struct Cfg128x256 { static constexpr int WM = 2, WN = 4, TM = 4, TN = 4; };   // half-height tiles for the last, partial round
+struct CfgW4 { static constexpr int WM = 1, WN = 4, TM = 8, TN = 4; };        // 128 x 256 on 4 waves: two independent workgroups per CU
 
 template <int BK> __device__ __forceinline__ int swz(int row);
 // BK = 64: 128-byte rows, 8 chunks of 16 B; BK = 32: 64-byte rows, 4 chunks.  See DESIGN.md "LDS images".
@@ -46,13 +51,15 @@ template <int TERMS, int BK, class CFG>
 struct Tile {
   static constexpr int BM = CFG::WM * CFG::TM * 16, BN = CFG::WN * CFG::TN * 16;
   static constexpr int THREADS = CFG::WM * CFG::WN * 64;
-  static constexpr int NP = (TERMS == 3) ? 2 : 1;           // planes per operand: hi (+ lo)
-  static constexpr int PLANE_A = BM * BK * 2, PLANE_W = BN * BK * 2;   // bytes
-  static constexpr int OFF_W = NP * PLANE_A;
-  static constexpr int STAGE = NP * (PLANE_A + PLANE_W);
+  static constexpr int NP = (TERMS == 3) ? 2 : 1;           // planes of the A operand: hi (+ lo)
+  static constexpr int PLANE_A = BM * BK * 2;               // bytes
+  static constexpr int STAGE = NP * PLANE_A;                // only A is staged in LDS
   static constexpr int CPR = BK / 8;                        // 16-byte chunks per row
   static constexpr int ITERS_A = (BM * CPR) / THREADS;      // LDS-DMA instructions per thread per plane
-  static constexpr int ITERS_W = (BN * CPR) / THREADS;
+  static constexpr int KS = BK / 32;                        // MFMA k-steps per K-tile
+  static constexpr int NA = NP * ITERS_A;                   // A DMA pieces per thread per K-tile
+  static constexpr int NB = NP * KS * CFG::TN;              // W fragment loads per lane per K-tile
+  static constexpr int LDS_BYTES = (2 * STAGE > CFG::WM * CFG::WN * 16 * 68 * 4) ? 2 * STAGE : CFG::WM * CFG::WN * 16 * 68 * 4;
 };
 
 __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
@@ -60,16 +67,18 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-// Per-thread staging state: the rows a thread copies are the same for every K-tile, so the (row-mapped) source
-// pointers are computed once per K-segment and only advanced by BK elements per K-tile.
+// Per-thread state of the operand streams.  The rows a thread copies are the same for every K-tile, so the (row-mapped)
+// A source pointers are computed once per K-segment and advanced by BK elements per K-tile; the W fragment pointer of
+// the lane (its n-tile row of fragment blocks) likewise.
 template <int TERMS, int BK, class CFG>
 struct Stager {
   using T = Tile<TERMS, BK, CFG>;
   const bf16_t* a_hi[T::ITERS_A]; const bf16_t* a_lo[T::ITERS_A];
-  const bf16_t* w_hi[T::ITERS_W]; const bf16_t* w_lo[T::ITERS_W];
+  const bf16_t* w_hi; const bf16_t* w_lo;     // lane's 16 bytes of fragment block (n-tile of the wave's first column tile, k-step w_k0)
+  int64_t w_tile_stride;                       // elements between consecutive n-tiles = ksteps * 512
   int si, kk, nk;
 
-  __device__ __forceinline__ void open_segment(const GemmArgs& g, int seg, int m0, int n0, int wave, int lane) {
+  __device__ __forceinline__ void open_segment(const GemmArgs& g, int seg, int m0, int n0, int wc, int wave, int lane) {
 #ifdef AWT_DIAG_SAME_TILE   // every workgroup streams the same operand tiles: 100 % L2 hits (timing-only)
     m0 = 0; n0 = 0;
 #endif
@@ -89,61 +98,35 @@ struct Stager {
       a_hi[it] = ok ? sg.a_hi + aoff : nullptr;
       a_lo[it] = (ok && TERMS == 3) ? sg.a_lo + aoff : nullptr;
     }
-#pragma unroll
-    for (int it = 0; it < T::ITERS_W; ++it) {
-      const int p = it * T::THREADS + wave * 64 + lane;
-      const int row = p / T::CPR;
-      const int c = (p % T::CPR) ^ swz<BK>(row);
-      int n = n0 + row; n = n < g.N ? n : g.N - 1;
-      const int64_t woff = (int64_t)n * sg.ldw + c * 8;
-      w_hi[it] = sg.w_hi + woff;
-      w_lo[it] = (TERMS == 3) ? sg.w_lo + woff : nullptr;
-    }
+    w_tile_stride = (int64_t)sg.w_ksteps * 512;
+    const int nt0 = (n0 >> 4) + wc * CFG::TN;                   // the wave's first 16-column tile
+    const int64_t woff = ((int64_t)nt0 * sg.w_ksteps + sg.w_k0) * 512 + lane * 8;
+    w_hi = sg.w_hi + woff;
+    w_lo = (TERMS == 3) ? sg.w_lo + woff : nullptr;
   }
-  // One LDS-DMA instruction of the current K-tile (piece p of NPIECES).  Issuing the pieces one at a time between
-  // MFMA groups matters: a burst of all of them blocks the wave in VMEM issue for about as long as the transfer
-  // takes, and since instructions issue in order its MFMAs wait behind them (measured: tile time = DMA time + MFMA
-  // time for the burst form).
-  static constexpr int NPIECES = T::NP * (T::ITERS_A + T::ITERS_W);
-  template <int P>
-  __device__ __forceinline__ void stage_piece(const GemmArgs& g, char* stage_base, int wave) {
-    static_assert(P >= 0 && P < NPIECES, "piece index");
-    constexpr int plane = P % T::NP;                 // 0 = hi, 1 = lo
-    constexpr int q = P / T::NP;                     // 0 .. ITERS_A + ITERS_W - 1
-    const int koff = kk * BK;
-    if constexpr (q < T::ITERS_A) {
-      char* dst = stage_base + (q * T::THREADS + wave * 64) * 16 + plane * T::PLANE_A;
-      const bf16_t* src = plane == 0 ? a_hi[q] : a_lo[q];
-      glds16(src ? (const void*)(src + koff) : (const void*)g.zeros, dst);
+  // memory operation OP of the tile this stager points at: OP < NA is an A LDS-DMA piece, the rest are W fragment loads
+  template <int OP>
+  __device__ __forceinline__ void issue(const GemmArgs& g, char* stage_base, int wave, bf16x8 (&nbh)[T::KS][CFG::TN], bf16x8 (&nbl)[T::KS][CFG::TN]) {
+    static_assert(OP >= 0 && OP < T::NA + T::NB, "operation index");
+    if constexpr (OP < T::NA) {
+#ifndef AWT_DIAG_NO_DMA   // AWT_DIAG_*: timing-only builds of tools/build_variants.sh (wrong results), never shipped
+      constexpr int plane = OP % T::NP, it = OP / T::NP;
+      char* dst = stage_base + (it * T::THREADS + wave * 64) * 16 + plane * T::PLANE_A;
+      const bf16_t* src = plane == 0 ? a_hi[it] : a_lo[it];
+      glds16(src ? (const void*)(src + kk * BK) : (const void*)g.zeros, dst);
+#endif
     } else {
-      constexpr int it = q - T::ITERS_A;
-      char* dst = stage_base + T::OFF_W + (it * T::THREADS + wave * 64) * 16 + plane * T::PLANE_W;
-      glds16((plane == 0 ? w_hi[it] : w_lo[it]) + koff, dst);
-    }
-  }
-  __device__ __forceinline__ void advance(const GemmArgs& g, int m0, int n0, int wave, int lane) {
-    if (++kk == nk && si + 1 < g.nseg) open_segment(g, si + 1, m0, n0, wave, lane);
-  }
-  // copy the current K-tile into `stage_base`, then step to the next K-tile (opening the next segment if needed)
-  __device__ __forceinline__ void stage_and_advance(const GemmArgs& g, char* stage_base, int m0, int n0, int wave, int lane) {
-    const int koff = kk * BK;
-#pragma unroll
-    for (int it = 0; it < T::ITERS_A; ++it) {
-      char* dst = stage_base + (it * T::THREADS + wave * 64) * 16;
-      glds16(a_hi[it] ? (const void*)(a_hi[it] + koff) : (const void*)g.zeros, dst);
-#ifndef AWT_DIAG_SKIP_LO_DMA
-      if (TERMS == 3) glds16(a_lo[it] ? (const void*)(a_lo[it] + koff) : (const void*)g.zeros, dst + T::PLANE_A);
+#ifndef AWT_DIAG_NO_WLOAD
+      constexpr int q = OP - T::NA;
+      constexpr int plane = q % T::NP, r = q / T::NP, j = r % CFG::TN, ks = r / CFG::TN;
+      const int64_t off = (int64_t)j * w_tile_stride + (int64_t)(kk * T::KS + ks) * 512;
+      if (plane == 0) nbh[ks][j] = *reinterpret_cast<const bf16x8*>(w_hi + off);
+      else nbl[ks][j] = *reinterpret_cast<const bf16x8*>(w_lo + off);
 #endif
     }
-#pragma unroll
-    for (int it = 0; it < T::ITERS_W; ++it) {
-      char* dst = stage_base + T::OFF_W + (it * T::THREADS + wave * 64) * 16;
-      glds16(w_hi[it] + koff, dst);
-#ifndef AWT_DIAG_SKIP_LO_DMA
-      if (TERMS == 3) glds16(w_lo[it] + koff, dst + T::PLANE_W);
-#endif
-    }
-    if (++kk == nk && si + 1 < g.nseg) open_segment(g, si + 1, m0, n0, wave, lane);
+  }
+  __device__ __forceinline__ void advance(const GemmArgs& g, int m0, int n0, int wc, int wave, int lane) {
+    if (++kk == nk && si + 1 < g.nseg) open_segment(g, si + 1, m0, n0, wc, wave, lane);
   }
 };
 
@@ -234,7 +217,10 @@ __device__ __forceinline__ void store_out4(const GemmOut& o, int m, int n, float
 template <int TERMS, int BK, int EPI, class CFG>
 __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, 2) void gemm_kernel(GemmArgs g) {
   using T = Tile<TERMS, BK, CFG>;
-  constexpr int TM = CFG::TM, TN = CFG::TN;
+  using ST = Stager<TERMS, BK, CFG>;
+  constexpr int TM = CFG::TM, TN = CFG::TN, KS = T::KS, STEPS = KS * TM, NOPS = T::NA + T::NB;
+  constexpr int OPS_PER_STEP = (NOPS + STEPS - 1) / STEPS;
+  static_assert(TM == 4 || TM == 8, "steps are unrolled by hand");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -245,7 +231,7 @@ __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, 2) void gemm_kernel(GemmArg
   const int q = nwg >> 3, r = nwg & 7;
   const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
-  const int m0 = g.m_begin + tm * T::BM, n0 = tn * T::BN;
+  const int m0 = tm * T::BM, n0 = tn * T::BN;
 
   int ktiles = 0;
   for (int s = 0; s < g.nseg; ++s) ktiles += g.seg[s].K / BK;
@@ -259,175 +245,81 @@ __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, 2) void gemm_kernel(GemmArg
   const int wr = wave / CFG::WN, wc = wave - wr * CFG::WN;
   const int frow = lane & 15, fq = lane >> 4;
 
-  Stager<TERMS, BK, CFG> st;
-  st.open_segment(g, 0, m0, n0, wave, lane);
-  st.stage_and_advance(g, smem, m0, n0, wave, lane);
+  bf16x8 bh[KS][TN], bl[KS][TN], nbh[KS][TN], nbl[KS][TN], ah[2], al[2];
+  ST st;
+  st.open_segment(g, 0, m0, n0, wc, wave, lane);
+  // prologue: K-tile 0 -- A into LDS stage 0 (burst), W fragments into the "next" registers
+  auto issue_all = [&](char* stage) {
+    [&]<int... I>(std::integer_sequence<int, I...>) { (st.template issue<I>(g, stage, wave, nbh, nbl), ...); }(std::make_integer_sequence<int, NOPS>{});
+  };
+  issue_all(smem);
+  st.advance(g, m0, n0, wc, wave, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-#ifndef AWT_GEMM_PIPE
-#define AWT_GEMM_PIPE 1
-#endif
-  if constexpr (TERMS == 3 && AWT_GEMM_PIPE) {
-    // ---- software-pipelined K loop (BK = 32: one MFMA k-step per K-tile).
-    // A K-tile is TM steps; step i = A row-tile i (hi, lo) x the wave's TN B fragments x 3 products = 12 MFMAs.
-    //  * the A fragments of step i + 1 are read from LDS while step i's MFMAs issue (two register sets), so only the
-    //    first reads of a tile (B fragments + A_0, right after the barrier) are exposed;
-    //  * the LDS-DMA of the NEXT K-tile is issued one piece per step, never as a burst (a burst blocks the wave in VMEM
-    //    issue and its MFMAs queue behind it);
-    //  * one barrier per K-tile, after the tile's last MFMAs.
-    static_assert(BK == 32 && (TM % 2) == 0, "pipelined loop assumes one k-step per tile and an even number of steps");
-    using ST = Stager<TERMS, BK, CFG>;
-    constexpr int PPS = (ST::NPIECES + TM - 1) / TM;     // DMA pieces per step
-    bf16x8 bh[TN], bl[TN], ah[2], al[2];
-    const int arow0 = wr * TM * 16 + frow;       // + 16 i
-    auto load_b = [&](const char* stage) {
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int row = (wc * TN + j) * 16 + frow;
-        const int off = row * 64 + ((fq ^ swz<32>(row)) << 4);
-        bh[j] = *reinterpret_cast<const bf16x8*>(stage + T::OFF_W + off);
-        bl[j] = *reinterpret_cast<const bf16x8*>(stage + T::OFF_W + T::PLANE_W + off);
-      }
-    };
-    auto load_a = [&](const char* stage, int i, bf16x8& h, bf16x8& l) {
-      const int row = arow0 + 16 * i;
-      const int off = row * 64 + ((fq ^ swz<32>(row)) << 4);
-      h = *reinterpret_cast<const bf16x8*>(stage + off);
-      l = *reinterpret_cast<const bf16x8*>(stage + T::PLANE_A + off);
-    };
-    auto step = [&](auto i_t, const char* cur, char* nxt, bool has_next) {
-      constexpr int i = decltype(i_t)::value;
-      // a (free) use of this step's A fragments: the compiler's wait for them lands HERE, where they have had a whole
-      // step to arrive, instead of behind the next step's reads
-      asm volatile("" ::"v"(ah[i & 1]), "v"(al[i & 1]));
-#ifndef AWT_DIAG_NO_LDSREAD   // AWT_DIAG_*: timing-only builds of tools/build_variants.sh (wrong results), never shipped
-      if constexpr (i + 1 < TM) load_a(cur, i + 1, ah[(i + 1) & 1], al[(i + 1) & 1]);
-#endif
-#ifdef AWT_DIAG_NO_DMA
-      if (false) {
-#else
-      if (has_next) {
-#endif
-        if constexpr (i * PPS < ST::NPIECES) st.template stage_piece<(i * PPS < ST::NPIECES ? i * PPS : 0)>(g, nxt, wave);
-        if constexpr (PPS > 1 && i * PPS + 1 < ST::NPIECES) st.template stage_piece<(i * PPS + 1 < ST::NPIECES ? i * PPS + 1 : 0)>(g, nxt, wave);
-      }
-      __builtin_amdgcn_sched_barrier(0);   // reads / DMA of this step are issued before its MFMAs
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i & 1], bl[j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i & 1], bh[j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i & 1], bh[j], acc[i][j], 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    for (int kt = 0; kt < ktiles; ++kt) {
-      const char* cur = smem + (kt & 1) * T::STAGE;
-      char* nxt = smem + ((kt + 1) & 1) * T::STAGE;
-      const bool has_next = kt + 1 < ktiles;
+  const int arow0 = wr * TM * 16 + frow;       // + 16 i
+  auto load_a = [&](const char* stage, int ks, int i, bf16x8& h, bf16x8& l) {
+    const int row = arow0 + 16 * i;
+    const int off = row * (BK * 2) + (((ks * 4 + fq) ^ swz<BK>(row)) << 4);
+    h = *reinterpret_cast<const bf16x8*>(stage + off);
+    if (TERMS == 3) l = *reinterpret_cast<const bf16x8*>(stage + T::PLANE_A + off);
+  };
+  // step s = (ks, i): A row-tile i at k-step ks against the wave's TN W fragments
+  auto step = [&](auto s_t, const char* cur, char* nxt, bool has_next) {
+    constexpr int s = decltype(s_t)::value, ks = s / TM, i = s % TM;
+    // a (free) use of this step's A fragments: the compiler's wait for them lands HERE, where they have had a whole
+    // step to arrive, instead of behind the next step's reads
+    if (TERMS == 3) asm volatile("" ::"v"(ah[s & 1]), "v"(al[s & 1]));
+    else asm volatile("" ::"v"(ah[s & 1]));
 #ifndef AWT_DIAG_NO_LDSREAD
-      load_b(cur);
-      load_a(cur, 0, ah[0], al[0]);
-#else
-      if (kt == 0) { load_b(cur); load_a(cur, 0, ah[0], al[0]); ah[1] = ah[0]; al[1] = al[0]; }
+    if constexpr (s + 1 < STEPS) load_a(cur, (s + 1) / TM, (s + 1) % TM, ah[(s + 1) & 1], al[(s + 1) & 1]);
 #endif
-      static_assert(TM == 4 || TM == 8, "steps are unrolled by hand");
-      step(std::integral_constant<int, 0>{}, cur, nxt, has_next);
-      step(std::integral_constant<int, 1>{}, cur, nxt, has_next);
-      step(std::integral_constant<int, 2>{}, cur, nxt, has_next);
-      step(std::integral_constant<int, 3>{}, cur, nxt, has_next);
-      if constexpr (TM == 8) {
-        step(std::integral_constant<int, 4>{}, cur, nxt, has_next);
-        step(std::integral_constant<int, 5>{}, cur, nxt, has_next);
-        step(std::integral_constant<int, 6>{}, cur, nxt, has_next);
-        step(std::integral_constant<int, 7>{}, cur, nxt, has_next);
+    if (has_next) {   // this step's share of the next K-tile's memory operations (never a burst: see the header)
+      [&]<int... O>(std::integer_sequence<int, O...>) {
+        ([&] {
+          constexpr int op = s * OPS_PER_STEP + O;
+          if constexpr (op < NOPS) st.template issue<op>(g, nxt, wave, nbh, nbl);
+        }(), ...);
+      }(std::make_integer_sequence<int, OPS_PER_STEP>{});
+    }
+    __builtin_amdgcn_sched_barrier(0);   // reads / loads of this step are issued before its MFMAs
+#ifdef AWT_GEMM_TERM_OUTER
+    if (TERMS == 3) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s & 1], bl[ks][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[s & 1], bh[ks][j], acc[i][j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s & 1], bh[ks][j], acc[i][j], 0, 0, 0);
+#else
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      if (TERMS == 3) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s & 1], bl[ks][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[s & 1], bh[ks][j], acc[i][j], 0, 0, 0);
       }
-      if (has_next) st.advance(g, m0, n0, wave, lane);
+      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s & 1], bh[ks][j], acc[i][j], 0, 0, 0);
+    }
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  for (int kt = 0; kt < ktiles; ++kt) {
+    const char* cur = smem + (kt & 1) * T::STAGE;
+    char* nxt = smem + ((kt + 1) & 1) * T::STAGE;
+    const bool has_next = kt + 1 < ktiles;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) { bh[ks][j] = nbh[ks][j]; if (TERMS == 3) bl[ks][j] = nbl[ks][j]; }
+    load_a(cur, 0, 0, ah[0], al[0]);
+    [&]<int... S>(std::integer_sequence<int, S...>) { (step(std::integral_constant<int, S>{}, cur, nxt, has_next), ...); }(std::make_integer_sequence<int, STEPS>{});
+    if (has_next) st.advance(g, m0, n0, wc, wave, lane);
 #ifndef AWT_DIAG_NO_BARRIER
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
 #endif
-    }
-  } else {
-    // ---- stepped K loop: a K-tile is (BK / 32) x TM steps; step (ks, i) reads A row-tile i and issues TN (x3) MFMAs.
-    // The LDS-DMA of the NEXT K-tile is issued one piece per step instead of as a burst at the top of the tile.
-    using ST = Stager<TERMS, BK, CFG>;
-    constexpr int KS = BK / 32, STEPS = KS * TM;
-    constexpr int PPS = (ST::NPIECES + STEPS - 1) / STEPS;     // pieces per step
-    for (int kt = 0; kt < ktiles; ++kt) {
-      char* cur = smem + (kt & 1) * T::STAGE;
-      char* nxt = smem + ((kt + 1) & 1) * T::STAGE;
-      const bool has_next = kt + 1 < ktiles;
-      const char* a_hi = cur;
-      const char* a_lo = cur + T::PLANE_A;
-      const char* w_hi = cur + T::OFF_W;
-      const char* w_lo = cur + T::OFF_W + T::PLANE_W;
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        bf16x8 bh[TN], bl[TN];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int row = (wc * TN + j) * 16 + frow;
-          const int off = row * (BK * 2) + (((ks * 4 + fq) ^ swz<BK>(row)) << 4);
-          bh[j] = *reinterpret_cast<const bf16x8*>(w_hi + off);
-          if (TERMS == 3) bl[j] = *reinterpret_cast<const bf16x8*>(w_lo + off);
-        }
-        auto step = [&](auto i_t) {
-          constexpr int i = decltype(i_t)::value;
-#ifdef AWT_DIAG_NO_COMPUTE
-          return;
-#endif
-          bf16x8 ah, al;
-          const int row = (wr * TM + i) * 16 + frow;
-          const int off = row * (BK * 2) + (((ks * 4 + fq) ^ swz<BK>(row)) << 4);
-          ah = *reinterpret_cast<const bf16x8*>(a_hi + off);
-          if (TERMS == 3) al = *reinterpret_cast<const bf16x8*>(a_lo + off);
-#pragma unroll
-          for (int j = 0; j < TN; ++j) {
-#ifndef AWT_DIAG_ONE_MFMA
-            if (TERMS == 3) {
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[i][j], 0, 0, 0);
-            }
-#else
-            asm volatile("" ::"v"(al), "v"(bl[j]));
-#endif
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
-          }
-        };
-        // steps with their share of the next tile's DMA pieces (compile-time piece indices)
-        auto pieces = [&](auto s_t) {
-          constexpr int sidx = decltype(s_t)::value;
-#ifdef AWT_DIAG_NO_DMA
-          if (false) {
-#else
-          if (has_next) {
-#endif
-            if constexpr (sidx * PPS + 0 < ST::NPIECES) st.template stage_piece<sidx * PPS + 0>(g, nxt, wave);
-            if constexpr (PPS > 1 && sidx * PPS + 1 < ST::NPIECES) st.template stage_piece<(sidx * PPS + 1 < ST::NPIECES ? sidx * PPS + 1 : 0)>(g, nxt, wave);
-          }
-        };
-        auto run = [&](auto ks_t) {
-          constexpr int k = decltype(ks_t)::value;
-          static_assert(TM == 4 || TM == 8, "steps are unrolled by hand");
-          pieces(std::integral_constant<int, k * TM + 0>{}); step(std::integral_constant<int, 0>{});
-          pieces(std::integral_constant<int, k * TM + 1>{}); step(std::integral_constant<int, 1>{});
-          pieces(std::integral_constant<int, k * TM + 2>{}); step(std::integral_constant<int, 2>{});
-          pieces(std::integral_constant<int, k * TM + 3>{}); step(std::integral_constant<int, 3>{});
-          if constexpr (TM == 8) {
-            pieces(std::integral_constant<int, k * TM + 4>{}); step(std::integral_constant<int, 4>{});
-            pieces(std::integral_constant<int, k * TM + 5>{}); step(std::integral_constant<int, 5>{});
-            pieces(std::integral_constant<int, k * TM + 6>{}); step(std::integral_constant<int, 6>{});
-            pieces(std::integral_constant<int, k * TM + 7>{}); step(std::integral_constant<int, 7>{});
-          }
-        };
-        if (ks == 0) run(std::integral_constant<int, 0>{});
-        else run(std::integral_constant<int, (KS > 1 ? 1 : 0)>{});
-      }
-      if (has_next) st.advance(g, m0, n0, wave, lane);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-    }
   }
 
   // epilogue: the C/D layout of the 16x16 MFMA (col = lane & 15, row = (lane >> 4) * 4 + reg) would give 2-4 byte
@@ -470,43 +362,25 @@ int launch_one(GemmArgs a, hipStream_t s) {
   using T = Tile<TERMS, BK, CFG>;
   static bool attr = false;
   if (!attr) {
-    AWT_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_kernel<TERMS, BK, EPI, CFG>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * T::STAGE));
+    AWT_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_kernel<TERMS, BK, EPI, CFG>, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
     attr = true;
   }
-  a.tiles_m = (a.M - a.m_begin + T::BM - 1) / T::BM;
+  a.tiles_m = (a.M + T::BM - 1) / T::BM;
   a.tiles_n = (a.N + T::BN - 1) / T::BN;
-  hipLaunchKernelGGL((gemm_kernel<TERMS, BK, EPI, CFG>), dim3(a.tiles_m * a.tiles_n), dim3(T::THREADS), 2 * T::STAGE, s, a);
+  hipLaunchKernelGGL((gemm_kernel<TERMS, BK, EPI, CFG>), dim3(a.tiles_m * a.tiles_n), dim3(T::THREADS), T::LDS_BYTES, s, a);
   AWT_HIP_CHECK(hipGetLastError());
   return AWT_OK;
 }
 
 int g_force_tile = 0;  // 0 = auto, 128 / 256 = forced (tuning and tests)
 
-// 256 x 256 tiles on 256 CUs: a launch is ceil(tiles / 256) rounds long, and the encoder's shapes leave the last round
-// 18 - 58 % full (N = 768: 1125 tiles = 4.39 rounds -> 5).  When it pays, the rows of the partial round are computed
-// by a second launch with 128 x 256 tiles, which spreads them over twice as many CUs for half as long.
-constexpr int kCUs = 256;
+// Large shapes (every encoder GEMM at batch size >= 2) use 128 x 256 tiles on 4 waves, two workgroups per CU; the rest
+// (N = 128 LoRA projections, N = 384 models, tiny M) use 128 x 128.
 template <int EPI>
 int launch_epi(GemmArgs a, int terms, hipStream_t s) {
   const bool big = g_force_tile ? g_force_tile == 256 : (a.N % 256 == 0 && a.M >= 2048);
-  a.m_begin = 0;
   if (!big) return terms == 3 ? launch_one<3, 32, EPI, Cfg128>(a, s) : launch_one<1, 64, EPI, Cfg128>(a, s);
-  const int tn = a.N / 256, tm = (a.M + 255) / 256, tiles = tm * tn;
-  const int full_rounds = tiles / kCUs;
-  const int tm_main = full_rounds * kCUs / tn;                 // row panels whose tiles fill whole rounds
-  const int rows_left = a.M - tm_main * 256;
-  const int tail_tiles = ((rows_left + 127) / 128) * tn;
-  // rounds (in units of a 256 x 256 tile's duration): one launch vs main + half-height tail
-  const double one = (double)((tiles + kCUs - 1) / kCUs);
-  const double split = (double)((tm_main * tn + kCUs - 1) / kCUs) + 0.5 * (double)((tail_tiles + kCUs - 1) / kCUs) + 0.05;
-  if (full_rounds >= 1 && rows_left > 0 && split < one) {
-    GemmArgs m = a; m.M = tm_main * 256;
-    int rc = terms == 3 ? launch_one<3, 32, EPI, Cfg256>(m, s) : launch_one<1, 64, EPI, Cfg256>(m, s);
-    if (rc) return rc;
-    GemmArgs t = a; t.m_begin = tm_main * 256;
-    return terms == 3 ? launch_one<3, 32, EPI, Cfg128x256>(t, s) : launch_one<1, 64, EPI, Cfg128x256>(t, s);
-  }
-  return terms == 3 ? launch_one<3, 32, EPI, Cfg256>(a, s) : launch_one<1, 64, EPI, Cfg256>(a, s);
+  return terms == 3 ? launch_one<3, 32, EPI, CfgW4>(a, s) : launch_one<1, 64, EPI, CfgW4>(a, s);
 }
 
 bf16_t* g_zeros = nullptr;
@@ -531,7 +405,8 @@ int launch_gemm(awt_ctx* c, int M, int N, const GemmSeg* segs, int nseg, int ter
     a.seg[i] = segs[i];
     AWT_REQUIRE(segs[i].K > 0 && segs[i].K % 64 == 0, AWT_ERR_INVALID, "gemm: every K-segment must be a positive multiple of 64");
     AWT_REQUIRE(segs[i].a_hi && segs[i].w_hi && (terms == 1 || (segs[i].a_lo && segs[i].w_lo)), AWT_ERR_INVALID, "gemm: null operand plane");
-    AWT_REQUIRE(segs[i].lda % 8 == 0 && segs[i].ldw % 8 == 0, AWT_ERR_INVALID, "gemm: leading dimensions must be multiples of 8 elements");
+    AWT_REQUIRE(segs[i].lda % 8 == 0 && segs[i].w_ksteps > 0 && segs[i].w_k0 >= 0 && segs[i].w_k0 + segs[i].K / 32 <= segs[i].w_ksteps, AWT_ERR_INVALID,
+                "gemm: lda must be a multiple of 8 and the segment must lie inside its fragment-major weight matrix");
     AWT_REQUIRE(segs[i].rows_out > 0 && segs[i].rows_in > 0, AWT_ERR_INVALID, "gemm: bad row map");
     ksum += segs[i].K;
   }

@@ -6,7 +6,7 @@ P=mlx8-ws-audio-transformer_amd; mkdir -p $P/variants
 python -m mlx8_ws_audio_transformer_amd.build > /dev/null
 i=0
 for flags in "$@"; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc $flags -c $P/csrc/gemm.hip -o $P/variants/gemm_v$i.o 2>/dev/null
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++20 -fPIC -fno-gpu-rdc $flags -c $P/csrc/gemm.hip -o $P/variants/gemm_v$i.o 2>/dev/null
   objs=$(ls $P/csrc/_obj/*.o | grep -v gemm.o)
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $P/variants/libawt_v$i.so $objs $P/variants/gemm_v$i.o
   echo "v$i: $flags"

@@ -10,7 +10,7 @@ x = torch.randn(m, k, device="cuda"); w = torch.randn(n, k, device="cuda") * k *
 for _ in range(20): ops.linear(x, w, None, "bf16x3")
 torch.cuda.synchronize()
 PY
-for v in 0 1 2 3; do
+for v in $(seq 0 $(( $(ls mlx8-ws-audio-transformer_amd/variants/libawt_v*.so | wc -l) - 1 ))); do
   export AWT_LIB=$PWD/mlx8-ws-audio-transformer_amd/variants/libawt_v$v.so
   timeout -k 10 200 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d gpurun_out/clk_$v -- python3 /tmp/one_gemm.py > gpurun_out/clk_$v.log 2>&1
   python3 - gpurun_out/clk_$v $v <<'PY'

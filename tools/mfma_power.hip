@@ -1,0 +1,60 @@
+// Power / rate microbenchmark: which bf16 MFMA shape is cheaper per flop on gfx950?  (timing-only, tools/gpu_mfma_power.sh)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <chrono>
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+template <int SHAPE>
+__global__ __launch_bounds__(256, 2) void k(const bf16x8* in, float* out, int iters) {
+  bf16x8 a[4], b[4];
+  for (int i = 0; i < 4; ++i) { a[i] = in[threadIdx.x + 256 * i]; b[i] = in[threadIdx.x + 256 * (4 + i)]; }
+  if constexpr (SHAPE == 16) {
+    f32x4 acc[32];
+    for (int i = 0; i < 32; ++i) acc[i] = (f32x4){0, 0, 0, 0};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int i = 0; i < 32; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i & 3], b[(i >> 2) & 3], acc[i], 0, 0, 0);
+    }
+    float s = 0;
+    for (int i = 0; i < 32; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+  } else {
+    f32x16 acc[8];
+    for (int i = 0; i < 8; ++i) for (int j = 0; j < 16; ++j) acc[i][j] = 0;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[(i + r) & 3], b[(i >> 1) & 3], acc[i], 0, 0, 0);
+    }
+    float s = 0;
+    for (int i = 0; i < 8; ++i) for (int j = 0; j < 16; ++j) s += acc[i][j];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+  }
+}
+
+int main(int argc, char** argv) {
+  const int shape = atoi(argv[1]); const double secs = atof(argv[2]);
+  bf16x8* in; float* out;
+  hipMalloc(&in, 2048 * 16); hipMalloc(&out, 512 * 256 * 4);
+  unsigned short* h = (unsigned short*)malloc(2048 * 16);
+  srand(1);
+  for (int i = 0; i < 2048 * 8; ++i) h[i] = (unsigned short)(0x3f00 + (rand() & 0xff) + ((rand() & 1) << 15));   // random mantissas, |x| in [0.5, 1)
+  hipMemcpy(in, h, 2048 * 16, hipMemcpyHostToDevice);
+  const int iters = 20000;   // x 32 MFMAs (16x16x32) or 16 (32x32x16): same flops per iteration
+  auto t0 = std::chrono::steady_clock::now(); long n = 0;
+  while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < secs) {
+    for (int r = 0; r < 10; ++r) {
+      if (shape == 16) hipLaunchKernelGGL(k<16>, dim3(512), dim3(256), 0, 0, in, out, iters);
+      else hipLaunchKernelGGL(k<32>, dim3(512), dim3(256), 0, 0, in, out, iters);
+    }
+    hipDeviceSynchronize(); n += 10;
+  }
+  const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  const double flops = (double)n * 512 * 4 * iters * 32 * 16384.0;
+  printf("shape %d: %.1f TFLOP/s\n", shape, flops / dt / 1e12);
+  return 0;
+}
