@@ -29,7 +29,11 @@ constexpr int kThreads = 256;
 constexpr int QT = AWT_ATTN_QT;   // 32-query tiles per wave (K / V fragments, LDS tiles and the barrier are amortised over QT x 48 MFMAs)
 constexpr int QW = 32 * QT;       // queries per wave
 constexpr int QB = 4 * QW;        // queries per workgroup
-constexpr int KB = 64;            // keys per tile
+#ifndef AWT_ATTN_KB
+#define AWT_ATTN_KB 64
+#endif
+constexpr int KB = AWT_ATTN_KB;   // keys per tile (32 or 64)
+constexpr int NSUB = KB / 32;     // 32-key sub-tiles per tile
 constexpr int PLANE = KB * 64 * 2;  // 8 KiB: [64 keys][64 dims] bf16
 
 struct AttnArgs {
@@ -46,20 +50,25 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// One K/V tile, global -> LDS.  The source address is a wave-uniform tile base (SGPRs) plus a 32-bit per-lane offset, so the
+// eight DMA instructions share two offset VGPRs instead of eight 64-bit address pairs.
 template <int TERMS>
 __device__ __forceinline__ void stage_kv(const AttnArgs& a, int64_t head_off, int kt, char* stage, int wave, int lane) {
+  const int64_t tile_off = head_off + (int64_t)kt * (KB * 64);
+  const bf16_t* kh = a.k_hi + tile_off; const bf16_t* kl = a.k_lo + tile_off;
+  const bf16_t* vh = a.v_hi + tile_off; const bf16_t* vl = a.v_lo + tile_off;
+  const int last = a.S - 1 - kt * KB;          // rows past the sequence end re-read its last key (masked in the tail tile)
 #pragma unroll
-  for (int it = 0; it < 2; ++it) {
+  for (int it = 0; it < NSUB; ++it) {
     const int p = it * kThreads + wave * 64 + lane;
     const int row = p >> 3;
     const int c = (p & 7) ^ swz(row);
-    int key = kt * KB + row; key = key < a.S ? key : a.S - 1;
-    const int64_t off = head_off + (int64_t)key * 64 + c * 8;
+    const unsigned off = (unsigned)(min(row, last) * 64 + c * 8);
     char* dst = stage + (it * kThreads + wave * 64) * 16;
-    glds16(a.k_hi + off, dst);
-    if (TERMS == 3) glds16(a.k_lo + off, dst + PLANE);
-    glds16(a.v_hi + off, dst + (TERMS == 3 ? 2 : 1) * PLANE);
-    if (TERMS == 3) glds16(a.v_lo + off, dst + 3 * PLANE);
+    glds16(kh + off, dst);
+    if (TERMS == 3) glds16(kl + off, dst + PLANE);
+    glds16(vh + off, dst + (TERMS == 3 ? 2 : 1) * PLANE);
+    if (TERMS == 3) glds16(vl + off, dst + 3 * PLANE);
   }
 }
 
@@ -120,6 +129,15 @@ __global__ __launch_bounds__(kThreads, 2) void attention_kernel(AttnArgs a) {
   const int voffx = voff ^ 64;
 
   const int ntiles = (a.S + KB - 1) / KB;
+#ifdef AWT_ATTN_STAGGER
+  // the two waves of a SIMD (one from each of the CU's two workgroups) alternate between an MFMA phase and a VALU phase of
+  // equal length; started together they stay in step and never overlap.  Delay the odd wave slot of the first round.
+  {
+    unsigned hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    if ((int)blockIdx.x < AWT_ATTN_STAGGER_BLOCKS && (hwid & 1)) __builtin_amdgcn_s_sleep(AWT_ATTN_STAGGER);
+  }
+#endif
   stage_kv<TERMS>(a, head_off, 0, smem, wave, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -136,9 +154,9 @@ __global__ __launch_bounds__(kThreads, 2) void attention_kernel(AttnArgs a) {
     const char* v_lo = cur + 3 * PLANE;
 
     // ---- S^T = K Q^T : two 32-key sub-tiles, rows = keys, cols (lanes) = queries; q carries log2(e), so S is in log2 units
-    f32x16 sacc[QT][2];
+    f32x16 sacc[QT][NSUB];
 #pragma unroll
-    for (int kt2 = 0; kt2 < 2; ++kt2) {
+    for (int kt2 = 0; kt2 < NSUB; ++kt2) {
 #pragma unroll
       for (int t = 0; t < QT; ++t) sacc[t][kt2] = (f32x16){};
 #pragma unroll
@@ -149,10 +167,14 @@ __global__ __launch_bounds__(kThreads, 2) void attention_kernel(AttnArgs a) {
         if (TERMS == 3) kl = *reinterpret_cast<const bf16x8*>(k_lo + off);
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
+#ifdef AWT_DIAG_ATTN_NO_CROSS   // timing-only: one product per fragment pair, lo operands still loaded / computed
+          if (TERMS == 3) asm volatile("" ::"v"(kl), "v"(qlo[t][ks]));
+#else
           if (TERMS == 3) {
             sacc[t][kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qlo[t][ks], sacc[t][kt2], 0, 0, 0);
             sacc[t][kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh[t][ks], sacc[t][kt2], 0, 0, 0);
           }
+#endif
           sacc[t][kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[t][ks], sacc[t][kt2], 0, 0, 0);
         }
       }
@@ -163,7 +185,7 @@ __global__ __launch_bounds__(kThreads, 2) void attention_kernel(AttnArgs a) {
     for (int t = 0; t < QT; ++t) {
       float tmax = -1.0e30f;
 #pragma unroll
-      for (int kt2 = 0; kt2 < 2; ++kt2)
+      for (int kt2 = 0; kt2 < NSUB; ++kt2)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           if (TAIL) {
@@ -178,10 +200,14 @@ __global__ __launch_bounds__(kThreads, 2) void attention_kernel(AttnArgs a) {
       m_run[t] = m_new;
       float psum = 0.f;
 #pragma unroll
-      for (int kt2 = 0; kt2 < 2; ++kt2)
+      for (int kt2 = 0; kt2 < NSUB; ++kt2)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
+#ifdef AWT_DIAG_ATTN_NO_EXP   // timing-only
+          const float pv = sacc[t][kt2][r] - m_new;
+#else
           const float pv = __builtin_amdgcn_exp2f(sacc[t][kt2][r] - m_new);
+#endif
           sacc[t][kt2][r] = pv;
           psum += pv;
         }
@@ -197,7 +223,7 @@ __global__ __launch_bounds__(kThreads, 2) void attention_kernel(AttnArgs a) {
     //      V^T fragments come from the transpose read: 16-lane group g covers dims 16 (g & 1) .. + 15 of the dim-tile for
     //      lane-half g >> 1; lane 4 qq + pp of the group supplies row (key) qq, columns 4 pp .. 4 pp + 3.
 #pragma unroll
-    for (int kt2 = 0; kt2 < 2; ++kt2)
+    for (int kt2 = 0; kt2 < NSUB; ++kt2)
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         bf16x8 ph[QT], pl[QT];
@@ -224,10 +250,14 @@ __global__ __launch_bounds__(kThreads, 2) void attention_kernel(AttnArgs a) {
           }
 #pragma unroll
           for (int t = 0; t < QT; ++t) {
+#ifdef AWT_DIAG_ATTN_NO_CROSS
+            if (TERMS == 3) asm volatile("" ::"v"(vl), "v"(pl[t]));
+#else
             if (TERMS == 3) {
               oacc[t][et] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl[t], oacc[t][et], 0, 0, 0);
               oacc[t][et] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph[t], oacc[t][et], 0, 0, 0);
             }
+#endif
             oacc[t][et] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph[t], oacc[t][et], 0, 0, 0);
           }
         }

@@ -24,6 +24,8 @@
 // * 1-D grid with an XCD-aware remap: consecutive tiles of one A row-panel run on one XCD.
 // * epilogue: accumulators are transposed through a per-wave LDS patch so every store is a whole 128 - 256 B row
 //   segment; side inputs are prefetched one strip ahead.
+#include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 #include "common.h"
 
@@ -33,6 +35,7 @@ constexpr int kMaxSeg = 3;
 
 struct GemmArgs {
   int M, N, nseg, tiles_m, tiles_n;
+  int group_n;           // > 0: walk tiles in groups of group_n column tiles (weight slice L2-resident); 0: groups of GM row panels
   GemmSeg seg[kMaxSeg];
   GemmOut out;
   const bf16_t* zeros;   // >= 128 zero bytes (padding rows of the conv stem)
@@ -230,7 +233,27 @@ __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, 2) void gemm_kernel(GemmArg
   const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
   const int q = nwg >> 3, r = nwg & 7;
   const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+#ifndef AWT_GEMM_GM
+#define AWT_GEMM_GM 4
+#endif
+  // Tile order inside an XCD's run (launch_one picks it from the shape):
+  //  group_n = 0 (default): groups of GM row panels, row panel fastest -- GM activation panels stay L2-resident and each
+  //    weight tile is read by GM workgroups at once.
+  //  group_n > 0: groups of group_n column tiles, walked row panel by row panel: the group's weight slice stays in the
+  //    XCD's 4 MB L2 for the whole pass over M; the activations are streamed tiles_n / group_n times.
+  constexpr int GM = AWT_GEMM_GM;
+  int tm, tn;
+  if (g.group_n > 0) {
+    const int grp = tile / (g.group_n * g.tiles_m);
+    const int gn = min(g.group_n, g.tiles_n - grp * g.group_n);
+    const int within = tile - grp * g.group_n * g.tiles_m;
+    tm = within / gn; tn = grp * g.group_n + (within - tm * gn);
+  } else {
+    const int grp = tile / (GM * g.tiles_n);
+    const int gm = min(GM, g.tiles_m - grp * GM);
+    const int within = tile - grp * GM * g.tiles_n;
+    tn = within / gm; tm = grp * GM + (within - tn * gm);
+  }
   const int m0 = tm * T::BM, n0 = tn * T::BN;
 
   int ktiles = 0;
@@ -357,6 +380,12 @@ __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, 2) void gemm_kernel(GemmArg
   }
 }
 
+int g_force_tile = 0;  // 0 = auto, 128 / 256 = forced (tuning and tests)
+// Tile order (see the kernel).  Measured on the encoder's shapes (tools/gemm_traffic_shapes.sh, profiles/r01_gemm_tile_order.txt):
+// column-tile groups of 3 cut the L2 -> fabric reads by 10 - 25 % but run 1.5 % slower end to end than groups of GM = 4 row
+// panels, so row-panel groups are the default; AWT_GEMM_GROUP_N=n selects column groups for experiments.
+int g_group_n = 0;
+
 template <int TERMS, int BK, int EPI, class CFG>
 int launch_one(GemmArgs a, hipStream_t s) {
   using T = Tile<TERMS, BK, CFG>;
@@ -367,12 +396,12 @@ int launch_one(GemmArgs a, hipStream_t s) {
   }
   a.tiles_m = (a.M + T::BM - 1) / T::BM;
   a.tiles_n = (a.N + T::BN - 1) / T::BN;
+  a.group_n = g_group_n;
   hipLaunchKernelGGL((gemm_kernel<TERMS, BK, EPI, CFG>), dim3(a.tiles_m * a.tiles_n), dim3(T::THREADS), T::LDS_BYTES, s, a);
   AWT_HIP_CHECK(hipGetLastError());
   return AWT_OK;
 }
 
-int g_force_tile = 0;  // 0 = auto, 128 / 256 = forced (tuning and tests)
 
 // Large shapes (every encoder GEMM at batch size >= 2) use 128 x 256 tiles on 4 waves, two workgroups per CU; the rest
 // (N = 128 LoRA projections, N = 384 models, tiny M) use 128 x 128.
@@ -395,6 +424,7 @@ int launch_gemm(awt_ctx* c, int M, int N, const GemmSeg* segs, int nseg, int ter
   AWT_REQUIRE(nseg >= 1 && nseg <= kMaxSeg, AWT_ERR_INVALID, "gemm: 1..3 K-segments");
   AWT_REQUIRE(terms == 1 || terms == 3, AWT_ERR_INVALID, "gemm: terms must be 1 or 3");
   if (!g_zeros) {
+    if (const char* e = getenv("AWT_GEMM_GROUP_N")) g_group_n = std::max(0, atoi(e));   // tile-order experiments (tools/)
     AWT_HIP_CHECK(hipMalloc((void**)&g_zeros, 256));
     AWT_HIP_CHECK(hipMemset(g_zeros, 0, 256));
   }

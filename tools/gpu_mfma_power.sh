@@ -1,6 +1,6 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT"
-for shape in 16 32; do
+for shape in ${SHAPES:-16 32}; do
   timeout -k 10 60 tools/_bin/mfma_power $shape 8 &
   pid=$!
   sleep 4
