@@ -72,6 +72,18 @@ int awt_logmel_generic(awt_ctx* c, const float* pcm, int64_t pcm_stride, int B, 
                        int n_fft, int hop, int n_mels, float f_min, float f_max, float log_eps, float* out,
                        void* stream);
 
+/* Mono mix + sample-rate conversion + pad / trim (K16).  Stands behind /root/reference/.charles/spectrogram.py:146-157:
+ *   `torch.mean(waveform, dim=0, keepdim=True)` when there is more than one channel, then
+ *   `torchaudio.transforms.Resample(orig_freq=sr, new_freq=SAMPLE_RATE)(waveform)` when sr differs (transform defaults:
+ *   sinc_interp_hann, lowpass_filter_width 6, rolloff 0.99), then zero-pad / truncate to `n_out` samples.
+ * pcm: `channels` channels of `n_in` samples, int16 (scaled by 1/32768 as torchaudio.load does) or float32; element
+ *   (c, i) is at pcm[c * channel_stride + i * sample_stride] -- planar [C][n] is (n, 1), interleaved WAV data is (1, C).
+ * out: float32 [n_out].  The resampled clip has awt_resampled_length() = ceil(n_in * sr_out / sr_in) samples; output
+ *   samples beyond it are zero.  sr_in == sr_out skips the filter, as the reference does. */
+int64_t awt_resampled_length(int n_in, int sr_in, int sr_out);
+int awt_prepare_waveform(awt_ctx* c, const void* pcm, int pcm_is_i16, int channels, int64_t channel_stride,
+                         int64_t sample_stride, int n_in, int sr_in, int sr_out, float* out, int n_out, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------
  * Whisper-style audio encoder (K5-K13).  Stands behind `encoder(input_features).last_hidden_state`
  * (`WhisperModel.get_encoder()`, .charles/music2midi/model.py:33,109-110; implicitly AB/fineTune.py:199)

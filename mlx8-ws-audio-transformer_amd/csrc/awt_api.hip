@@ -103,6 +103,16 @@ extern "C" int awt_logmel_generic(awt_ctx* c, const float* pcm, int64_t pcm_stri
                              (hipStream_t)stream);
 }
 
+extern "C" int64_t awt_resampled_length(int n_in, int sr_in, int sr_out) {
+  if (n_in <= 0 || sr_in <= 0 || sr_out <= 0) return 0;
+  return resampled_length(n_in, sr_in, sr_out);
+}
+extern "C" int awt_prepare_waveform(awt_ctx* c, const void* pcm, int pcm_is_i16, int channels, int64_t channel_stride,
+                                    int64_t sample_stride, int n_in, int sr_in, int sr_out, float* out, int n_out, void* stream) {
+  return prepare_waveform_impl(c, pcm, pcm_is_i16, channels, channel_stride, sample_stride, n_in, sr_in, sr_out, out, n_out,
+                               (hipStream_t)stream);
+}
+
 // ------------------------------------------------------------------------------------------------ encoder
 namespace {
 

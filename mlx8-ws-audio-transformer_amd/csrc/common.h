@@ -152,6 +152,9 @@ int logmel_whisper_impl(awt_ctx* c, const void* pcm, int pcm_is_i16, int64_t pcm
                         int max_valid, int B, int n_frames_out, float* out, void* workspace, size_t ws_bytes, hipStream_t s);
 int logmel_generic_impl(awt_ctx* c, const float* pcm, int64_t pcm_stride, int B, int n_samples, int sample_rate, int n_fft,
                         int hop, int n_mels, float f_min, float f_max, float log_eps, float* out, hipStream_t s);
+int prepare_waveform_impl(awt_ctx* c, const void* pcm, int pcm_is_i16, int channels, int64_t channel_stride, int64_t sample_stride,
+                          int n_in, int sr_in, int sr_out, float* out, int n_out, hipStream_t s);
+int64_t resampled_length(int n_in, int sr_in, int sr_out);
 void awt_free_tables(awt_ctx* c);
 void awt_gemm_force_tile(int t);  // 0 auto, 128 or 256: tuning / tests
 

@@ -208,12 +208,15 @@ std::vector<double> linspace(double a, double b, int n) {
 
 struct MelTable { int* start; int* count; int* off; double* w; };
 struct BasisTable { double* basis; int n_bin_tiles; };
+// polyphase resampling filter: taps[phase][K] fp32 (torchaudio's kernel), and per phase the range of non-zero taps
+struct ResampleTable { float* taps; int* first; int* count; int orig, out, width, K; };
 
 }  // namespace
 
 struct awt_ctx::Table {
   std::map<int, BasisTable> basis;                                                   // key n_fft
   std::map<std::tuple<int, int, int, int, int, int>, MelTable> mel;                  // n_bins, n_mels, fmin*8, fmax*8, sr, slaney
+  std::map<std::pair<int, int>, ResampleTable> resample;                             // (sr_in, sr_out) / gcd
   std::vector<void*> allocs;
 };
 
@@ -384,4 +387,115 @@ int logmel_generic_impl(awt_ctx* c, const float* pcm, int64_t pcm_stride, int B,
   ProfScope prof(c, AWT_PROF_LOGMEL, s, 2.0 * 2.0 * n_fft * p.n_bins * (double)p.T_out * B);
   // every frame of the (un-padded) generic front-end is live: n_valid == L makes live_frames() == T_out
   return launch_stage1<1>(p, B, p.T_out, s);
+}
+
+// ------------------------------------------------------------------------------------------ mono mix + resampling (K16)
+// Stands behind /root/reference/.charles/spectrogram.py:146-157: channel mean, torchaudio.transforms.Resample(sr -> 16000)
+// with its defaults (sinc_interp_hann, lowpass_filter_width 6, rolloff 0.99), zero-pad / truncate.  torchaudio evaluates
+// the filter as a stride-`orig` conv1d over all K = 2 width + orig taps of each of the `out` phases; only the taps inside
+// the Hann window (|t| < 6) are non-zero, so each output sample here sums 13 - 73 taps instead of 15 - 475.
+// HBM-bound and tiny (0.13 - 0.77 MB read, 0.26 MB written per 4 s clip): one thread per output sample.
+namespace {
+
+template <bool I16>
+__global__ __launch_bounds__(256) void resample_mono_kernel(const void* pcm, int channels, int64_t cstride, int64_t sstride,
+                                                            int n_in, ResampleTable t, int n_res, float* out, int n_out) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= n_out) return;
+  if (n >= n_res) { out[n] = 0.f; return; }
+  auto sample = [&](int m) {            // channel mean of input sample m, as torch.mean(waveform, dim=0): sum, then divide
+    float sum = 0.f;
+    for (int c = 0; c < channels; ++c) {
+      const int64_t off = c * cstride + m * sstride;
+      sum += I16 ? (float)reinterpret_cast<const int16_t*>(pcm)[off] * (1.0f / 32768.0f) : reinterpret_cast<const float*>(pcm)[off];
+    }
+    return channels > 1 ? sum / (float)channels : sum;
+  };
+  if (t.taps == nullptr) { out[n] = sample(n); return; }   // equal rates: the reference skips the resampler
+  const int j = n / t.out, ph = n - j * t.out;
+  const int base = j * t.orig - t.width;                   // tap k multiplies input sample base + k (zero outside the clip)
+  const float* taps = t.taps + (int64_t)ph * t.K;
+  const int k0 = t.first[ph], k1 = k0 + t.count[ph];
+  float acc = 0.f;
+  for (int k = max(k0, -base); k < k1; ++k) {
+    const int m = base + k;
+    if (m >= n_in) break;
+    acc = fmaf(taps[k], sample(m), acc);
+  }
+  out[n] = acc;
+}
+
+int get_resample(awt_ctx* c, int sr_in, int sr_out, ResampleTable* out) {
+  if (!c->tables) c->tables = new awt_ctx::Table();
+  int a = sr_in, b = sr_out;
+  while (b) { const int r = a % b; a = b; b = r; }
+  const int orig = sr_in / a, outp = sr_out / a;
+  auto it = c->tables->resample.find({orig, outp});
+  if (it != c->tables->resample.end()) { *out = it->second; return AWT_OK; }
+  // torchaudio.functional._get_sinc_resample_kernel, dtype=None: float64 arithmetic (the phase term i / new is an int64
+  // tensor divided by an int, i.e. rounded to float32 first), result rounded to float32
+  const double lpw = 6.0, rolloff = 0.99;
+  const double basef = (double)(orig < outp ? orig : outp) * rolloff;
+  const int width = (int)ceil(lpw * orig / basef);
+  const int K = 2 * width + orig;
+  std::vector<float> taps((size_t)outp * K);
+  std::vector<int> first(outp), count(outp);
+  for (int i = 0; i < outp; ++i) {
+    const double phase = (double)((float)(-i) / (float)outp);
+    int lo = K, hi = -1;
+    for (int k = 0; k < K; ++k) {
+      double t = (phase + (double)(k - width) / (double)orig) * basef;
+      t = t < -lpw ? -lpw : (t > lpw ? lpw : t);
+      const double cw = cos(t * M_PI / lpw / 2.0);
+      const double window = cw * cw;
+      const double tp = t * M_PI;
+      const double sinc = tp == 0.0 ? 1.0 : sin(tp) / tp;
+      const float v = (float)(sinc * window * (basef / (double)orig));
+      taps[(size_t)i * K + k] = v;
+      if (v != 0.f) { if (k < lo) lo = k; hi = k; }
+    }
+    first[i] = hi < 0 ? 0 : lo; count[i] = hi < 0 ? 0 : hi - lo + 1;
+  }
+  ResampleTable t{}; t.orig = orig; t.out = outp; t.width = width; t.K = K;
+  AWT_HIP_CHECK(hipMalloc((void**)&t.taps, taps.size() * sizeof(float))); c->tables->allocs.push_back(t.taps);
+  AWT_HIP_CHECK(hipMalloc((void**)&t.first, outp * sizeof(int)));         c->tables->allocs.push_back(t.first);
+  AWT_HIP_CHECK(hipMalloc((void**)&t.count, outp * sizeof(int)));         c->tables->allocs.push_back(t.count);
+  AWT_HIP_CHECK(hipMemcpy(t.taps, taps.data(), taps.size() * sizeof(float), hipMemcpyHostToDevice));
+  AWT_HIP_CHECK(hipMemcpy(t.first, first.data(), outp * sizeof(int), hipMemcpyHostToDevice));
+  AWT_HIP_CHECK(hipMemcpy(t.count, count.data(), outp * sizeof(int), hipMemcpyHostToDevice));
+  c->tables->resample[{orig, outp}] = t;
+  *out = t;
+  return AWT_OK;
+}
+
+}  // namespace
+
+int64_t resampled_length(int n_in, int sr_in, int sr_out) {   // ceil(new * n / orig), torchaudio's target_length
+  int a = sr_in, b = sr_out;
+  while (b) { const int r = a % b; a = b; b = r; }
+  const int64_t orig = sr_in / a, outp = sr_out / a;
+  return ((int64_t)outp * n_in + orig - 1) / orig;
+}
+
+int prepare_waveform_impl(awt_ctx* c, const void* pcm, int pcm_is_i16, int channels, int64_t channel_stride, int64_t sample_stride,
+                          int n_in, int sr_in, int sr_out, float* out, int n_out, hipStream_t s) {
+  AWT_REQUIRE(c && pcm && out, AWT_ERR_INVALID, "prepare_waveform: null argument");
+  AWT_REQUIRE(channels >= 1 && channels <= 8 && n_in > 0 && n_out > 0, AWT_ERR_INVALID, "prepare_waveform: need 1..8 channels, n_in > 0, n_out > 0");
+  AWT_REQUIRE(sr_in >= 1000 && sr_in <= 768000 && sr_out >= 1000 && sr_out <= 768000, AWT_ERR_INVALID, "prepare_waveform: sample rates must be in 1 kHz .. 768 kHz");
+  ResampleTable t{};
+  int n_res = n_in;
+  if (sr_in != sr_out) {
+    int rc = get_resample(c, sr_in, sr_out, &t); if (rc) return rc;
+    AWT_REQUIRE((int64_t)t.out * t.K <= (1 << 22), AWT_ERR_INVALID, "prepare_waveform: rate pair needs too large a filter table");
+    const int64_t r = resampled_length(n_in, sr_in, sr_out);
+    n_res = r > n_out ? n_out : (int)r;
+  } else if (n_res > n_out) {
+    n_res = n_out;
+  }
+  ProfScope prof(c, AWT_PROF_LOGMEL, s, 0.0);
+  const dim3 grid((n_out + 255) / 256);
+  if (pcm_is_i16) hipLaunchKernelGGL(resample_mono_kernel<true>, grid, dim3(256), 0, s, pcm, channels, channel_stride, sample_stride, n_in, t, n_res, out, n_out);
+  else hipLaunchKernelGGL(resample_mono_kernel<false>, grid, dim3(256), 0, s, pcm, channels, channel_stride, sample_stride, n_in, t, n_res, out, n_out);
+  AWT_HIP_CHECK(hipGetLastError());
+  return AWT_OK;
 }

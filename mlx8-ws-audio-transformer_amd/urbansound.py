@@ -4,7 +4,8 @@
   the reference's defaults (spectrogram.py:56-62);
 * `mel_spectrogram_log(waveform)`  = `torch.log(mel_spectrogram(waveform) + 1e-6)` (spectrogram.py:79-87,160-162),
   computed by libawt's `awt_logmel_generic` (periodic Hann, center / reflect, power 2, HTK mel, no norm);
-* `prepare_waveform` = mono mean + pad / trim to DURATION (spectrogram.py:145-157; resampling is out of scope);
+* `prepare_waveform` = mono mean + `Resample(sr -> SAMPLE_RATE)` + pad / trim to DURATION (spectrogram.py:145-157);
+  libawt's `awt_prepare_waveform` whenever the clip is on the GPU or needs resampling;
 * `UrbanSoundDataSet(parquet_path=None, folds=None)` with `.df`, `.n_mels`, `__len__`, `__getitem__ ->
   (FloatTensor[n_mels, T], int)` over the reference's Parquet schema `rel_path, fold, class_id, class_name,
   log_mel_flat, log_mel_shape` (spectrogram.py:166-173,184-212).
@@ -39,19 +40,51 @@ def get_processed_parquet_path() -> str:
     return os.path.join(PROCESSED_PARQUET_PATH, get_processed_parquet_filename())
 
 
-def prepare_waveform(waveform: torch.Tensor, sample_rate: int = SAMPLE_RATE, duration: float = DURATION) -> torch.Tensor:
-    """[C, n] or [n] -> [1, int(sr * duration)]: channel mean, zero-pad or truncate (spectrogram.py:145-157)."""
-    w = waveform.float()
+def prepare_waveform(waveform: torch.Tensor, sample_rate: int = SAMPLE_RATE, duration: float = DURATION,
+                     target_rate: int = SAMPLE_RATE, interleaved: bool = False) -> torch.Tensor:
+    """[C, n] or [n] at `sample_rate` -> [1, int(target_rate * duration)] fp32: channel mean, resample to `target_rate`
+    (torchaudio.transforms.Resample defaults), zero-pad or truncate (spectrogram.py:145-157, in that order).
+
+    A CPU tensor already at the target rate takes the reference's three host tensor ops.  Anything else -- a device
+    tensor (int16 or float32; `interleaved=True` for WAV-order [n, C] data) or a clip that needs resampling -- goes
+    through libawt (`awt_prepare_waveform`) and comes back as a device tensor; there is no host resampler."""
+    n_out = int(target_rate * duration)
+    w = waveform
+    if not w.is_cuda and int(sample_rate) == int(target_rate) and not interleaved:
+        w = w.float()
+        if w.dim() == 1:
+            w = w.unsqueeze(0)
+        if w.shape[0] > 1:
+            w = torch.mean(w, dim=0, keepdim=True)
+        if w.shape[1] < n_out:
+            w = torch.nn.functional.pad(w, (0, n_out - w.shape[1]))
+        else:
+            w = w[:, :n_out]
+        return w
+    if w.dtype != torch.int16:
+        w = w.float()
     if w.dim() == 1:
-        w = w.unsqueeze(0)
-    if w.shape[0] > 1:
-        w = torch.mean(w, dim=0, keepdim=True)
-    n = int(sample_rate * duration)
-    if w.shape[1] < n:
-        w = torch.nn.functional.pad(w, (0, n - w.shape[1]))
+        w = w.unsqueeze(1) if interleaved else w.unsqueeze(0)
+    if not w.is_cuda:
+        w = w.cuda()
+    w = w.contiguous()
+    if interleaved:
+        n_in, channels = w.shape
+        cstride, sstride = 1, channels
     else:
-        w = w[:, :n]
-    return w
+        channels, n_in = w.shape
+        cstride, sstride = n_in, 1
+    out = torch.empty((1, n_out), dtype=torch.float32, device=w.device)
+    with torch.cuda.device(w.device):
+        _lib.check(_lib.lib().awt_prepare_waveform(_lib.ctx(w.device), _lib.ptr(w), int(w.dtype == torch.int16), channels, cstride,
+                                                   sstride, n_in, int(sample_rate), int(target_rate), _lib.ptr(out), n_out,
+                                                   _lib.stream_handle()))
+    return out
+
+
+def resampled_length(n_in: int, sample_rate: int, target_rate: int = SAMPLE_RATE) -> int:
+    """ceil(n_in * target_rate / sample_rate): the length torchaudio's Resample returns."""
+    return int(_lib.lib().awt_resampled_length(int(n_in), int(sample_rate), int(target_rate)))
 
 
 def mel_spectrogram_log(waveform: torch.Tensor, sample_rate: int = None, n_fft: int = None, hop_length: int = None,
