@@ -9,7 +9,9 @@ What is native here and what is not:
 * encoder forward + backward to the adapters: hand-written HIP via libawt (encoder.NativeWhisperEncoder, trainable=True);
 * decoder (self-attention + cross-attention over the 1500 encoder positions + tied vocabulary projection) and the
   cross-entropy: stock PyTorch-ROCm ops below -- the decoder is the "next" row of the scope table, not part of the hot
-  path, and it only has to carry d(loss)/d(encoder hidden states) back to the native backward;
+  path, and it only has to carry d(loss)/d(encoder hidden states) back to the native backward.  Its one encoder-sized
+  piece -- the cross-attention key / value projections of all 1500 encoder positions, 2 x layers GEMMs of
+  [B*1500, d] x [d, d] -- runs on libawt's GEMM as ONE fused projection (`_CrossKVProjection`), forward and backward;
 * AdamW on the adapter parameters: torch.optim.AdamW; learning-rate schedule: linear warm-up then linear decay, as HF's
   default `lr_scheduler_type="linear"`.
 
@@ -29,6 +31,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import ops
 from .dist import FlatGradBucket
 from .encoder import NativeWhisperEncoder
 from .weights import EncoderConfig, LoraSpec, unit_variates
@@ -47,6 +50,23 @@ def shift_tokens_right(labels: torch.Tensor, pad_token_id: int, decoder_start_to
     return shifted
 
 
+class _CrossKVProjection(torch.autograd.Function):
+    """Cross-attention keys and values of every decoder layer, `[k_0 | v_0 | k_1 | ...] = enc W_all^T + b_all`, as one
+    native GEMM ([B*S, d] x [d, 2*layers*d], HF:modeling_whisper.py:306-312 per layer), and d(enc) = dY W_all as one more.
+    The projection weights are frozen, so there is no weight gradient."""
+
+    @staticmethod
+    def forward(ctx, enc2d, w_all, b_all, precision):
+        ctx.save_for_backward(w_all)
+        ctx.precision = precision
+        return ops.linear(enc2d, w_all, b_all, precision)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (w_all,) = ctx.saved_tensors
+        return ops.linear(dy.contiguous(), w_all.t().contiguous(), None, ctx.precision), None, None, None
+
+
 class _DecoderLayer(nn.Module):
     def __init__(self, d: int, heads: int, ffn: int):
         super().__init__()
@@ -63,11 +83,12 @@ class _DecoderLayer(nn.Module):
         o = F.scaled_dot_product_attention(q, k, v, is_causal=causal)
         return o.transpose(1, 2).reshape(B, Lq, d)
 
-    def forward(self, x, enc):
+    def forward(self, x, enc, kv=None):
         y = self.ln1(x)
         x = x + self.self_o(self._attn(self.self_q(y), self.self_k(y), self.self_v(y), True))
         y = self.ln2(x)
-        x = x + self.cross_o(self._attn(self.cross_q(y), self.cross_k(enc), self.cross_v(enc), False))
+        k, v = kv if kv is not None else (self.cross_k(enc), self.cross_v(enc))
+        x = x + self.cross_o(self._attn(self.cross_q(y), k, v, False))
         y = self.ln3(x)
         return x + self.fc2(F.gelu(self.fc1(y)))
 
@@ -82,11 +103,22 @@ class WhisperDecoder(nn.Module):
         self.layers = nn.ModuleList([_DecoderLayer(d, heads, ffn) for _ in range(layers)])
         self.layer_norm = nn.LayerNorm(d)
 
-    def forward(self, input_ids: torch.Tensor, encoder_hidden_states: torch.Tensor) -> torch.Tensor:
+    def cross_kv(self, enc: torch.Tensor, precision: str):
+        """Per layer (k, v) [B, S, d] views of one fused native projection of the encoder output."""
+        B, S, d = enc.shape
+        w_all = torch.cat([w for l in self.layers for w in (l.cross_k.weight, l.cross_v.weight)], dim=0)
+        b_all = torch.cat([b for l in self.layers for b in (torch.zeros_like(l.cross_v.bias), l.cross_v.bias)], dim=0)
+        with torch.autocast("cuda", enabled=False):
+            kv = _CrossKVProjection.apply(enc.reshape(B * S, d).float(), w_all.float(), b_all.float(), precision)
+        parts = kv.view(B, S, 2 * len(self.layers), d).unbind(dim=2)     # unbind: its backward is one stack, not 2L zero-fills
+        return [(parts[2 * i], parts[2 * i + 1]) for i in range(len(self.layers))]
+
+    def forward(self, input_ids: torch.Tensor, encoder_hidden_states: torch.Tensor, native_precision: Optional[str] = None) -> torch.Tensor:
         L = input_ids.shape[1]
         x = self.embed_tokens(input_ids) + self.embed_positions.weight[:L]
-        for layer in self.layers:
-            x = layer(x, encoder_hidden_states)
+        kvs = self.cross_kv(encoder_hidden_states, native_precision) if native_precision else [None] * len(self.layers)
+        for layer, kv in zip(self.layers, kvs):
+            x = layer(x, encoder_hidden_states, kv)
         return F.linear(self.layer_norm(x), self.embed_tokens.weight)   # proj_out tied to the embedding
 
 
@@ -95,11 +127,13 @@ class WhisperLoRAModel(nn.Module):
     (HF:modeling_whisper.py:994-1100): shift labels right, encoder, decoder, tied projection, CE with ignore -100."""
 
     def __init__(self, cfg: EncoderConfig, lora: LoraSpec, precision: str = "bf16x3", device: str = "cuda", decoder_layers: Optional[int] = None,
-                 seed: int = 0, vocab: int = WHISPER_VOCAB, decoder_autocast: Optional[torch.dtype] = None):
+                 seed: int = 0, vocab: int = WHISPER_VOCAB, decoder_autocast: Optional[torch.dtype] = None, native_cross_kv: bool = True):
         super().__init__()
         # the decoder is stock PyTorch (scope row "next"): fp32 like the reference (fp16=False, fineTune.py:170) unless
         # decoder_autocast=torch.bfloat16 asks torch to run its matmuls in bf16
         self.decoder_autocast = decoder_autocast
+        self.native_cross_kv = native_cross_kv   # False: every decoder matmul on torch (the pre-fusion path, kept for A/B tests)
+        self.precision = precision
         self.encoder = NativeWhisperEncoder(cfg, precision=precision, lora=lora, device=device, seed=seed, trainable=True)
         torch.manual_seed(seed)
         self.decoder = WhisperDecoder(cfg.d_model, decoder_layers or cfg.layers, cfg.heads, cfg.ffn, vocab).to(device)
@@ -117,7 +151,7 @@ class WhisperLoRAModel(nn.Module):
             decoder_input_ids = shift_tokens_right(labels, self.config.pad_token_id, self.config.decoder_start_token_id)
         hidden = self.encoder(input_features).last_hidden_state
         with torch.autocast("cuda", dtype=self.decoder_autocast or torch.bfloat16, enabled=self.decoder_autocast is not None):
-            logits = self.decoder(decoder_input_ids.to(hidden.device), hidden)
+            logits = self.decoder(decoder_input_ids.to(hidden.device), hidden, self.precision if self.native_cross_kv else None)
         loss = None
         if labels is not None:
             loss = F.cross_entropy(logits.view(-1, logits.shape[-1]).float(), labels.to(hidden.device).reshape(-1), ignore_index=-100)

@@ -62,3 +62,24 @@ def test_sharded_gradients_average_to_full_batch_gradient():
     g_avg = (grads(halves[0]) + grads(halves[1])) / 2
     rel = (g_full - g_avg).abs().max() / g_full.abs().max()
     assert rel < 1e-3, float(rel)
+
+
+def test_native_cross_kv_projection_matches_torch_decoder():
+    """The fused native cross-attention K/V projection (one GEMM forward, one backward) gives the loss and the adapter
+    gradients of the all-torch decoder."""
+    from mlx8_ws_audio_transformer_amd.finetune import WhisperLoRAModel
+    cfg = wts.config("mini", True)
+    b = _batch(cfg, 3)
+    out = {}
+    for native in (True, False):
+        model = WhisperLoRAModel(cfg, wts.LoraSpec(r=8, alpha=16.0), decoder_layers=2, native_cross_kv=native)
+        for p in model.lora_parameters():
+            if p.shape[1] == 8:
+                with torch.no_grad():
+                    p.copy_(torch.from_numpy(0.05 * wts.unit_variates("kvtest", p.numel(), 1).reshape(p.shape).astype(np.float32)))
+        res = model(input_features=b["input_features"].cuda(), labels=b["labels"].cuda())
+        res.loss.backward()
+        out[native] = (float(res.loss.detach()), torch.cat([p.grad.flatten() for p in model.lora_parameters()]).cpu())
+    assert abs(out[True][0] - out[False][0]) < 2e-4 * abs(out[False][0])
+    ref = out[False][1]
+    assert float((out[True][1] - ref).abs().max()) < 2e-3 * float(ref.abs().max())
