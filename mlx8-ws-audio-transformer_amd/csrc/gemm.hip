@@ -8,21 +8,19 @@
 // * K-segments let one kernel serve: plain linears (1 segment), linears with a LoRA term
 //   ([x | u] . [W | B]^T, 2 segments) and the stride-2 conv stem as an implicit GEMM (3 taps = 3 segments whose
 //   source row is 2 s + tap - 1, rows outside the clip reading as zero).
-// * block tiles: 256 x 256 (8 waves as 2 x 4, each 128 x 64 = 8 x 4 tiles of v_mfma_f32_16x16x32_bf16; one workgroup
-//   per CU) for the large encoder shapes, 128 x 256 for the rows of a launch's last partial round, 128 x 128 (4 waves)
-//   for N not a multiple of 256.
-// * the two operands take DIFFERENT routes on purpose.  The per-CU global -> LDS DMA path tops out near 13 B/clk
-//   (measured: every variant of an all-LDS kernel ran at 22 - 30 GB/s of DMA per CU, and 64 KB of tiles per K-step of
-//   3072 MFMA cycles needs 21 B/clk).  So only the ACTIVATION tile goes through LDS (16-byte LDS-DMA, double buffered,
-//   rows XOR-swizzled on the source address and on the ds_read_b128); the WEIGHT fragments are read straight into
-//   registers from a fragment-major copy of the weights (w_frag_index in common.h: one coalesced 1 KB block per
-//   fragment), one K-tile ahead.  That halves the DMA bytes, removes a third of the LDS reads and leaves the LDS
-//   ring at 64 KB.
+// * block tiles: 128 x 256 on 4 waves (1 x 4, each wave 128 x 64 = 8 x 4 tiles of v_mfma_f32_16x16x32_bf16), 32 KB of LDS,
+//   so TWO independent workgroups share a CU and cover each other's barrier bubbles; 128 x 128 (4 waves, 2 x 2) for N
+//   not a multiple of 256 and for small M.
+// * the two operands take DIFFERENT routes on purpose.  Only the ACTIVATION tile goes through LDS (16-byte LDS-DMA,
+//   double buffered, rows XOR-swizzled on the source address and on the ds_read_b128); the WEIGHT fragments -- static
+//   within a step and owned by the library -- are read straight into registers from a fragment-major copy of the
+//   weights (w_frag_index in common.h: one coalesced 1 KB block per fragment), one K-tile ahead: no LDS write, LDS read
+//   or swizzle for half of the operand bytes.  (The kernel is power-limited, not schedule-limited: DESIGN.md 4.2.)
 // * K loop: a K-tile is (BK / 32) x TM steps of TN x TERMS MFMAs; the A fragments of the next step are read from LDS,
 //   and one or two of the next K-tile's memory operations (A DMA pieces, W fragment loads) are issued, before each
 //   step's MFMAs; one barrier per K-tile.
-// * 1-D grid with an XCD-aware remap: consecutive tiles of one A row-panel run on one XCD.
-// * epilogue: accumulators are transposed through a per-wave LDS patch so every store is a whole 128 - 256 B row
+// * 1-D grid with an XCD-aware remap (each XCD owns a contiguous run of tiles) walked in groups of 4 row panels.
+// * epilogue: accumulators are transposed through a per-wave LDS patch so every store is a whole 256 B row
 //   segment; side inputs are prefetched one strip ahead.
 #include <algorithm>
 #include <cstdlib>

@@ -17,7 +17,7 @@ TOL = {"bf16x3": 2e-5, "bf16": 1.5e-2}
 
 @pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 256, 192), (1500, 384, 768), (77, 128, 3072),
-                                   (2500, 768, 768), (4096, 256, 128), (3000, 2304, 768)])  # last three: 256 x 256 tile path
+                                   (2500, 768, 768), (4096, 256, 128), (3000, 2304, 768)])  # last three: 128 x 256 (4-wave) tile path
 def test_linear(precision, M, N, K):
     from mlx8_ws_audio_transformer_amd import ops
     x, w, b = _rand((M, K), 1), _rand((N, K), 2, K ** -0.5), _rand((N,), 3)
