@@ -186,11 +186,16 @@ def main():
     gemm_ms, gemm_n, gemm_flop = prof["gemm"]
     achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     terms = 3 if a.precision == "bf16x3" else 1
+    props = torch.cuda.get_device_properties(dev)
+    device_info = {"name": props.name, "arch": getattr(props, "gcnArchName", ""), "compute_units": props.multi_processor_count,
+                   "hbm_gib": round(props.total_memory / 2 ** 30, 1), "max_sclk_mhz": round(getattr(props, "clock_rate", 0) / 1e3),
+                   "note": "peaks used: 2.5 PFLOP/s dense bf16 MFMA, 8 TB/s HBM3E (MI355X_MICROARCH.md); the encoder runs at the "
+                           "1400 W package limit with sclk 1.9-2.1 GHz (DESIGN.md 4.2)"}
     result = {
         "metric": "4s@16kHz clips/sec through mel+Whisper-%s encoder" % a.model,
         "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16", "data": "synthetic",
+        "dtype": "bf16", "data": "synthetic", "device": device_info,
         "config": {"workload": "int16 PCM [B,64000] in HBM -> Whisper log-mel [B,80,%d] -> Whisper-%s encoder -> hidden [B,%d,%d] fp32"
                                % (cfg.n_frames, a.model, cfg.max_source_positions, cfg.d_model),
                    "mode": "trimmed (NOT reference-equivalent)" if a.trimmed else "parity (clip zero-padded to 30 s, as the reference computes)",

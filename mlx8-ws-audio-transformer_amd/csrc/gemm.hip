@@ -304,16 +304,6 @@ __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, 2) void gemm_kernel(GemmArg
       }(std::make_integer_sequence<int, OPS_PER_STEP>{});
     }
     __builtin_amdgcn_sched_barrier(0);   // reads / loads of this step are issued before its MFMAs
-#ifdef AWT_GEMM_TERM_OUTER
-    if (TERMS == 3) {
-#pragma unroll
-      for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s & 1], bl[ks][j], acc[i][j], 0, 0, 0);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[s & 1], bh[ks][j], acc[i][j], 0, 0, 0);
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s & 1], bh[ks][j], acc[i][j], 0, 0, 0);
-#else
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       if (TERMS == 3) {
@@ -322,7 +312,6 @@ __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, 2) void gemm_kernel(GemmArg
       }
       acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s & 1], bh[ks][j], acc[i][j], 0, 0, 0);
     }
-#endif
     __builtin_amdgcn_sched_barrier(0);
   };
 
