@@ -4,10 +4,10 @@
 namespace {
 
 // ------------------------------------------------------------------------------------------------ LayerNorm
-// One wave per row, the row lives in registers (d <= 1024): two-pass mean / variance in fp32 exactly like
+// One wave per row, the row lives in registers (d <= 1280): two-pass mean / variance in fp32 exactly like
 // torch.nn.functional.layer_norm (eps 1e-5, biased variance; HF:modeling_whisper.py:392,402,642), then affine.
 // Output is either fp32 (final layer_norm -> last_hidden_state) or bf16 hi (+ lo) planes for the next GEMM.
-constexpr int kLnMaxChunks = 4;  // float4 chunks per lane: d <= 64 * 4 * 4
+constexpr int kLnMaxChunks = 5;  // float4 chunks per lane: d <= 64 * 4 * 5 = 1280 (Whisper large)
 
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, int M, int d, float eps,
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256) void outer_reduce_final_kernel(const float* pa
 int launch_layernorm(awt_ctx* c, const float* x, const float* gamma, const float* beta, int M, int d, float eps,
                      float* out_f32, bf16_t* out_hi, bf16_t* out_lo, hipStream_t s) {
   AWT_REQUIRE(x && gamma && beta && (out_f32 || out_hi), AWT_ERR_INVALID, "layernorm: null argument");
-  AWT_REQUIRE(M > 0 && d > 0 && d % 4 == 0 && d <= 64 * 4 * kLnMaxChunks, AWT_ERR_INVALID, "layernorm: d must be a multiple of 4 and <= 1024");
+  AWT_REQUIRE(M > 0 && d > 0 && d % 4 == 0 && d <= 64 * 4 * kLnMaxChunks, AWT_ERR_INVALID, "layernorm: d must be a multiple of 4 and <= 1280");
   ProfScope prof(c, AWT_PROF_LAYERNORM, s, 0.0);
   hipLaunchKernelGGL(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, gamma, beta, M, d, eps, out_f32, out_hi, out_lo);
   AWT_HIP_CHECK(hipGetLastError());
@@ -331,7 +331,7 @@ int launch_im2col_conv1(awt_ctx* c, const float* mel, int B, int C, int T, int K
 int launch_layernorm_bwd(awt_ctx* c, const float* dy, const float* x, const float* gamma, const float* dres, int M, int d, float eps,
                          float* dx, bf16_t* dx_hi, bf16_t* dx_lo, hipStream_t s) {
   AWT_REQUIRE(dy && x && gamma && dx, AWT_ERR_INVALID, "layernorm_bwd: null argument");
-  AWT_REQUIRE(M > 0 && d > 0 && d % 4 == 0 && d <= 64 * 4 * kLnMaxChunks, AWT_ERR_INVALID, "layernorm_bwd: d must be a multiple of 4 and <= 1024");
+  AWT_REQUIRE(M > 0 && d > 0 && d % 4 == 0 && d <= 64 * 4 * kLnMaxChunks, AWT_ERR_INVALID, "layernorm_bwd: d must be a multiple of 4 and <= 1280");
   ProfScope prof(c, AWT_PROF_LAYERNORM, s, 0.0);
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, s, dy, x, gamma, dres, M, d, eps, dx, dx_hi, dx_lo);
   AWT_HIP_CHECK(hipGetLastError());

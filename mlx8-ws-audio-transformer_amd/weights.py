@@ -90,6 +90,8 @@ CONFIGS: Dict[str, EncoderConfig] = {
     "tiny": EncoderConfig(384, 4, 6, 1536, 80, 1500, "tiny"),
     "base": EncoderConfig(512, 6, 8, 2048, 80, 1500, "base"),
     "small": EncoderConfig(768, 12, 12, 3072, 80, 1500, "small"),
+    "medium": EncoderConfig(1024, 24, 16, 4096, 80, 1500, "medium"),
+    "large": EncoderConfig(1280, 32, 20, 5120, 80, 1500, "large"),   # large / large-v2 (80 mel bins; v3's 128 is not supported)
 }
 
 

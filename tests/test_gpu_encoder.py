@@ -27,7 +27,8 @@ def _native(cfg, precision, profile="test", lora=None, chunk=0):
 
 
 @pytest.mark.parametrize("name,trimmed,batch", [("mini", True, 2), ("mini", False, 1), ("tiny", True, 2), ("tiny", False, 2),
-                                                ("small", True, 2), ("small", False, 2)])
+                                                ("small", True, 2), ("small", False, 2), ("base", True, 2), ("base", False, 1),
+                                                ("medium", True, 1), ("medium", False, 1), ("large", True, 1)])
 def test_encoder_parity_mode_vs_oracle_and_golden(name, trimmed, batch):
     cfg = wts.config(name, trimmed)
     W = wts.init_encoder_weights(cfg, 0, "test")
@@ -37,7 +38,7 @@ def test_encoder_parity_mode_vs_oracle_and_golden(name, trimmed, batch):
     ref = oracle_enc.encoder_forward(W, mel, cfg.heads).numpy()
     e = oracle_enc.error_norms(out, ref)
     assert e["max_abs"] < PARITY_TOL, e
-    G = golden("encoder.npz")
+    G = golden("encoder.npz" if name in ("mini", "tiny", "small") else "encoder_large.npz")
     key = cfg.name
     np.testing.assert_allclose(out[:, :4], G[f"{key}/last_head"], rtol=0, atol=PARITY_TOL)
     np.testing.assert_allclose(out[:, -4:], G[f"{key}/last_tail"], rtol=0, atol=PARITY_TOL)

@@ -8,7 +8,7 @@ from mlx8_ws_audio_transformer_amd import weights as wts
 from oracle import encoder, logmel
 from tests.util import golden, piano_clips_f32
 
-G = golden("encoder.npz")
+G = {**golden("encoder.npz"), **golden("encoder_large.npz")}   # second file: base / medium / large (tools/make_golden.py encoder_large)
 
 
 def _mel(cfg, batch):
@@ -16,7 +16,8 @@ def _mel(cfg, batch):
 
 
 @pytest.mark.parametrize("name,trimmed,batch", [("mini", False, 1), ("mini", True, 2), ("tiny", True, 2),
-                                                ("tiny", False, 2), ("small", True, 2)])
+                                                ("tiny", False, 2), ("small", True, 2), ("base", True, 2),
+                                                ("medium", True, 1), ("large", True, 1)])
 def test_encoder_matches_reference(name, trimmed, batch):
     cfg = wts.config(name, trimmed)
     W = wts.init_encoder_weights(cfg, seed=0, profile="test")

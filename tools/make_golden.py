@@ -106,11 +106,16 @@ def encoder_mel(cfg: wts.EncoderConfig, batch: int):
     return fe(clips, sampling_rate=16000, return_tensors="np", max_length=n)["input_features"].astype(np.float32)
 
 
-def gen_encoder():
+ENCODER_CASES = [("mini", False, 1, True), ("mini", True, 2, True), ("tiny", False, 2, False), ("tiny", True, 2, False),
+                 ("small", False, 2, False), ("small", True, 2, False)]
+# the other Whisper sizes (own file, so the round-1 fixtures above stay byte-identical)
+ENCODER_CASES_LARGE = [("base", True, 2, False), ("base", False, 1, False), ("medium", True, 1, False), ("medium", False, 1, False),
+                       ("large", True, 1, False)]
+
+
+def gen_encoder(cases=ENCODER_CASES, fname="encoder.npz"):
     out = {}
-    for name, trimmed, batch, full in [("mini", False, 1, True), ("mini", True, 2, True),
-                                       ("tiny", False, 2, False), ("tiny", True, 2, False),
-                                       ("small", False, 2, False), ("small", True, 2, False)]:
+    for name, trimmed, batch, full in cases:
         cfg = wts.config(name, trimmed)
         W = wts.init_encoder_weights(cfg, seed=0, profile="test")
         enc = hf_encoder(cfg, W)
@@ -134,7 +139,7 @@ def gen_encoder():
     from transformers.models.whisper.modeling_whisper import sinusoids
     tab = sinusoids(1500, 768).numpy()
     out["sinusoid_rows_768"] = tab[[0, 1, 199, 1499]]
-    np.savez_compressed(os.path.join(GOLD, "encoder.npz"), **out)
+    np.savez_compressed(os.path.join(GOLD, fname), **out)
 
 
 def make_pad_tokenizer():
@@ -185,5 +190,7 @@ if __name__ == "__main__":
         gen_logmel()
     if "encoder" in what:
         gen_encoder()
+    if "encoder_large" in what:
+        gen_encoder(ENCODER_CASES_LARGE, "encoder_large.npz")
     if "collator" in what:
         gen_collator()
