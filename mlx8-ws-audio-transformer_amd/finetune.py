@@ -16,8 +16,11 @@ What is native here and what is not:
   default `lr_scheduler_type="linear"`.
 
 `Seq2SeqTrainingArguments` keeps the field names the reference passes (fineTune.py:162-183; `evaluation_strategy` and
-`tokenizer=` are the 4.35-era spellings).  Fields that drive subsystems outside the scope (generate-based eval, wandb,
-hub) are accepted and ignored, and `Seq2SeqTrainer.train()` says so once.
+`tokenizer=` are the 4.35-era spellings).  `evaluation_strategy="steps"` + `predict_with_generate` run `evaluate()` every
+`eval_steps`: eval loss, greedy `generate` (self-attention cache, cross-attention keys / values from the fused native
+projection) and the caller's `compute_metrics` (`wer()` below replaces `evaluate.load("wer")`), and
+`load_best_model_at_end` restores the best adapters.  wandb / hub fields are accepted and ignored.  The decoder, the
+loss and greedy decoding are pinned to `WhisperForConditionalGeneration` by tests/golden/decoder.npz.
 """
 from __future__ import annotations
 
@@ -39,6 +42,7 @@ from .weights import EncoderConfig, LoraSpec, unit_variates
 WHISPER_VOCAB = 51865
 DECODER_START = 50258   # <|startoftranscript|>
 PAD_ID = 50257
+EOS_ID = 50257          # <|endoftext|> (Whisper uses it as pad as well)
 
 
 def shift_tokens_right(labels: torch.Tensor, pad_token_id: int, decoder_start_token_id: int) -> torch.Tensor:
@@ -67,34 +71,52 @@ class _CrossKVProjection(torch.autograd.Function):
         return ops.linear(dy.contiguous(), w_all.t().contiguous(), None, ctx.precision), None, None, None
 
 
-class _DecoderLayer(nn.Module):
-    def __init__(self, d: int, heads: int, ffn: int):
+class _Attention(nn.Module):
+    """q/k/v/out projections under HF's names (`k_proj` has no bias, HF:modeling_whisper.py:262-282)."""
+
+    def __init__(self, d: int, heads: int):
         super().__init__()
         self.heads = heads
-        self.self_q, self.self_k, self.self_v, self.self_o = nn.Linear(d, d), nn.Linear(d, d, bias=False), nn.Linear(d, d), nn.Linear(d, d)
-        self.cross_q, self.cross_k, self.cross_v, self.cross_o = nn.Linear(d, d), nn.Linear(d, d, bias=False), nn.Linear(d, d), nn.Linear(d, d)
-        self.ln1, self.ln2, self.ln3 = nn.LayerNorm(d), nn.LayerNorm(d), nn.LayerNorm(d)
+        self.q_proj, self.k_proj = nn.Linear(d, d), nn.Linear(d, d, bias=False)
+        self.v_proj, self.out_proj = nn.Linear(d, d), nn.Linear(d, d)
+
+    def forward(self, x, kv_src=None, kv=None, causal=False, cache=None):
+        """`kv`: precomputed (k, v) [B, S, d]; `cache`: dict holding the self-attention keys / values of earlier positions."""
+        B, Lq, d = x.shape
+        hd = d // self.heads
+        if kv is None:
+            src = x if kv_src is None else kv_src
+            k, v = self.k_proj(src), self.v_proj(src)
+            if cache is not None:
+                if "k" in cache:
+                    k, v = torch.cat([cache["k"], k], dim=1), torch.cat([cache["v"], v], dim=1)
+                cache["k"], cache["v"] = k, v
+        else:
+            k, v = kv
+        q, k, v = (t.reshape(B, -1, self.heads, hd).transpose(1, 2) for t in (self.q_proj(x), k, v))
+        o = F.scaled_dot_product_attention(q, k, v, is_causal=causal and Lq > 1)
+        return self.out_proj(o.transpose(1, 2).reshape(B, Lq, d))
+
+
+class _DecoderLayer(nn.Module):
+    """HF:modeling_whisper.py:416-507 (pre-LN; module names are the state-dict keys of `WhisperDecoderLayer`)."""
+
+    def __init__(self, d: int, heads: int, ffn: int):
+        super().__init__()
+        self.self_attn, self.encoder_attn = _Attention(d, heads), _Attention(d, heads)
+        self.self_attn_layer_norm, self.encoder_attn_layer_norm, self.final_layer_norm = nn.LayerNorm(d), nn.LayerNorm(d), nn.LayerNorm(d)
         self.fc1, self.fc2 = nn.Linear(d, ffn), nn.Linear(ffn, d)
 
-    def _attn(self, q, k, v, causal):
-        B, Lq, d = q.shape
-        hd = d // self.heads
-        q, k, v = (t.view(B, -1, self.heads, hd).transpose(1, 2) for t in (q, k, v))
-        o = F.scaled_dot_product_attention(q, k, v, is_causal=causal)
-        return o.transpose(1, 2).reshape(B, Lq, d)
-
-    def forward(self, x, enc, kv=None):
-        y = self.ln1(x)
-        x = x + self.self_o(self._attn(self.self_q(y), self.self_k(y), self.self_v(y), True))
-        y = self.ln2(x)
-        k, v = kv if kv is not None else (self.cross_k(enc), self.cross_v(enc))
-        x = x + self.cross_o(self._attn(self.cross_q(y), k, v, False))
-        y = self.ln3(x)
-        return x + self.fc2(F.gelu(self.fc1(y)))
+    def forward(self, x, enc, kv=None, cache=None):
+        x = x + self.self_attn(self.self_attn_layer_norm(x), causal=True, cache=cache)
+        x = x + self.encoder_attn(self.encoder_attn_layer_norm(x), kv_src=enc, kv=kv)
+        return x + self.fc2(F.gelu(self.fc1(self.final_layer_norm(x))))
 
 
 class WhisperDecoder(nn.Module):
-    """Pre-LN Whisper decoder with tied output projection (HF:modeling_whisper.py:416-507,649-797), stock torch ops."""
+    """Pre-LN Whisper decoder with tied output projection (HF:modeling_whisper.py:416-507,649-797), stock torch ops.
+    Parameter names are HF's (`WhisperDecoder.state_dict()` loads unchanged); pinned to the reference by
+    tests/golden/decoder.npz."""
 
     def __init__(self, d: int, layers: int, heads: int, ffn: int, vocab: int = WHISPER_VOCAB, max_target_positions: int = 448):
         super().__init__()
@@ -106,19 +128,24 @@ class WhisperDecoder(nn.Module):
     def cross_kv(self, enc: torch.Tensor, precision: str):
         """Per layer (k, v) [B, S, d] views of one fused native projection of the encoder output."""
         B, S, d = enc.shape
-        w_all = torch.cat([w for l in self.layers for w in (l.cross_k.weight, l.cross_v.weight)], dim=0)
-        b_all = torch.cat([b for l in self.layers for b in (torch.zeros_like(l.cross_v.bias), l.cross_v.bias)], dim=0)
+        att = [l.encoder_attn for l in self.layers]
+        w_all = torch.cat([w for a in att for w in (a.k_proj.weight, a.v_proj.weight)], dim=0)
+        b_all = torch.cat([b for a in att for b in (torch.zeros_like(a.v_proj.bias), a.v_proj.bias)], dim=0)
         with torch.autocast("cuda", enabled=False):
             kv = _CrossKVProjection.apply(enc.reshape(B * S, d).float(), w_all.float(), b_all.float(), precision)
         parts = kv.view(B, S, 2 * len(self.layers), d).unbind(dim=2)     # unbind: its backward is one stack, not 2L zero-fills
         return [(parts[2 * i], parts[2 * i + 1]) for i in range(len(self.layers))]
 
-    def forward(self, input_ids: torch.Tensor, encoder_hidden_states: torch.Tensor, native_precision: Optional[str] = None) -> torch.Tensor:
+    def forward(self, input_ids: torch.Tensor, encoder_hidden_states: torch.Tensor, native_precision: Optional[str] = None,
+                cross=None, caches=None, position_offset: int = 0) -> torch.Tensor:
+        """`cross` / `caches` / `position_offset` serve incremental decoding (generate): precomputed cross-attention
+        (k, v) per layer, per-layer self-attention caches, and the position of input_ids[:, 0]."""
         L = input_ids.shape[1]
-        x = self.embed_tokens(input_ids) + self.embed_positions.weight[:L]
-        kvs = self.cross_kv(encoder_hidden_states, native_precision) if native_precision else [None] * len(self.layers)
-        for layer, kv in zip(self.layers, kvs):
-            x = layer(x, encoder_hidden_states, kv)
+        x = self.embed_tokens(input_ids) + self.embed_positions.weight[position_offset: position_offset + L]
+        if cross is None:
+            cross = self.cross_kv(encoder_hidden_states, native_precision) if native_precision else [None] * len(self.layers)
+        for i, layer in enumerate(self.layers):
+            x = layer(x, encoder_hidden_states, cross[i], None if caches is None else caches[i])
         return F.linear(self.layer_norm(x), self.embed_tokens.weight)   # proj_out tied to the embedding
 
 
@@ -127,7 +154,8 @@ class WhisperLoRAModel(nn.Module):
     (HF:modeling_whisper.py:994-1100): shift labels right, encoder, decoder, tied projection, CE with ignore -100."""
 
     def __init__(self, cfg: EncoderConfig, lora: LoraSpec, precision: str = "bf16x3", device: str = "cuda", decoder_layers: Optional[int] = None,
-                 seed: int = 0, vocab: int = WHISPER_VOCAB, decoder_autocast: Optional[torch.dtype] = None, native_cross_kv: bool = True):
+                 seed: int = 0, vocab: int = WHISPER_VOCAB, decoder_autocast: Optional[torch.dtype] = None, native_cross_kv: bool = True,
+                 max_target_positions: int = 448):
         super().__init__()
         # the decoder is stock PyTorch (scope row "next"): fp32 like the reference (fp16=False, fineTune.py:170) unless
         # decoder_autocast=torch.bfloat16 asks torch to run its matmuls in bf16
@@ -136,10 +164,10 @@ class WhisperLoRAModel(nn.Module):
         self.precision = precision
         self.encoder = NativeWhisperEncoder(cfg, precision=precision, lora=lora, device=device, seed=seed, trainable=True)
         torch.manual_seed(seed)
-        self.decoder = WhisperDecoder(cfg.d_model, decoder_layers or cfg.layers, cfg.heads, cfg.ffn, vocab).to(device)
+        self.decoder = WhisperDecoder(cfg.d_model, decoder_layers or cfg.layers, cfg.heads, cfg.ffn, vocab, max_target_positions).to(device)
         for p in self.decoder.parameters():
             p.requires_grad = False             # frozen base model: only the adapters train
-        self.config = SimpleNamespace(decoder_start_token_id=DECODER_START, pad_token_id=PAD_ID, d_model=cfg.d_model)
+        self.config = SimpleNamespace(decoder_start_token_id=DECODER_START, pad_token_id=PAD_ID, eos_token_id=EOS_ID, d_model=cfg.d_model)
 
     def lora_parameters(self) -> List[nn.Parameter]:
         return [p for n, p in self.encoder.named_parameters() if "lora_" in n]
@@ -156,6 +184,62 @@ class WhisperLoRAModel(nn.Module):
         if labels is not None:
             loss = F.cross_entropy(logits.view(-1, logits.shape[-1]).float(), labels.to(hidden.device).reshape(-1), ignore_index=-100)
         return SimpleNamespace(loss=loss, logits=logits, encoder_last_hidden_state=hidden)
+
+    @torch.no_grad()
+    def generate(self, input_features: torch.Tensor, max_length: int = 225, eos_token_id: Optional[int] = None,
+                 decoder_input_ids: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Greedy decoding as `model.generate(input_features)` is used at AB/wavToWhisper.py:59 / fineTuneMidiTester.py:34 and by
+        `predict_with_generate` (fineTune.py:172): encoder once, cross-attention keys / values once (the fused native
+        projection), then one token per step with a self-attention cache.  Returns [B, <= max_length] token ids, starting
+        with decoder_start_token_id; rows that have emitted `eos_token_id` are padded with pad_token_id."""
+        hidden = self.encoder(input_features).last_hidden_state
+        cross = self.decoder.cross_kv(hidden, self.precision) if self.native_cross_kv else None
+        with torch.autocast("cuda", dtype=self.decoder_autocast or torch.bfloat16, enabled=self.decoder_autocast is not None):
+            return greedy_decode(self.decoder, hidden, self.config.decoder_start_token_id, self.config.pad_token_id,
+                                 self.config.eos_token_id if eos_token_id is None else eos_token_id, max_length, cross=cross,
+                                 decoder_input_ids=decoder_input_ids)
+
+
+@torch.no_grad()
+def greedy_decode(dec: WhisperDecoder, hidden: torch.Tensor, start_id: int, pad_id: int, eos_id: int, max_length: int,
+                  cross=None, decoder_input_ids: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """argmax decoding with a self-attention cache; `cross` = per-layer (k, v) of `hidden` (computed here if None)."""
+    B = hidden.shape[0]
+    if cross is None:
+        cross = [(l.encoder_attn.k_proj(hidden), l.encoder_attn.v_proj(hidden)) for l in dec.layers]
+    ids = decoder_input_ids.to(hidden.device) if decoder_input_ids is not None else \
+        torch.full((B, 1), start_id, dtype=torch.long, device=hidden.device)
+    caches = [dict() for _ in dec.layers]
+    done = torch.zeros(B, dtype=torch.bool, device=hidden.device)
+    step_in, pos = ids, 0
+    while ids.shape[1] < max_length:
+        logits = dec(step_in, hidden, cross=cross, caches=caches, position_offset=pos)
+        pos += step_in.shape[1]
+        nxt = logits[:, -1].float().argmax(dim=-1)
+        nxt = torch.where(done, torch.full_like(nxt, pad_id), nxt)
+        ids = torch.cat([ids, nxt[:, None]], dim=1)
+        done = done | (nxt == eos_id)
+        if bool(done.all()):
+            break
+        step_in = nxt[:, None]
+    return ids
+
+
+def wer(references: List[str], predictions: List[str]) -> float:
+    """Word error rate = word-level edit distance summed over the pairs / reference words: what `evaluate.load("wer")`
+    (jiwer) returns at AB/fineTune.py:143-158 (the reference multiplies it by 100)."""
+    errors = words = 0
+    for ref, hyp in zip(references, predictions):
+        r, h = ref.split(), hyp.split()
+        prev = list(range(len(h) + 1))
+        for i, rw in enumerate(r, 1):
+            cur = [i] + [0] * len(h)
+            for j, hw in enumerate(h, 1):
+                cur[j] = min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (rw != hw))
+            prev = cur
+        errors += prev[len(h)]
+        words += len(r)
+    return errors / max(1, words)
 
 
 @dataclass
@@ -239,17 +323,68 @@ class Seq2SeqTrainer:
                 if idx:
                     yield self.data_collator([self.train_dataset[j] for j in idx])
 
+    @torch.no_grad()
+    def evaluate(self, eval_dataset=None) -> Dict[str, float]:
+        """`predict_with_generate` evaluation (fineTune.py:172-181): loss on the eval set, greedy generation up to
+        `generation_max_length`, then `compute_metrics(pred)` with `.predictions` / `.label_ids` as the reference's
+        `compute_metrics` reads them (fineTune.py:145-158).  Keys are prefixed `eval_` like HF's."""
+        ds = eval_dataset if eval_dataset is not None else self.eval_dataset
+        if ds is None or self.data_collator is None:
+            raise ValueError("evaluate() needs an eval_dataset and a data_collator")
+        dev = self.model.encoder.device
+        bs = self.args.per_device_eval_batch_size
+        was_training = self.model.training
+        self.model.eval()
+        losses, weights, preds, labels = [], [], [], []
+        for i in range(0, len(ds), bs):
+            batch = self.data_collator([ds[j] for j in range(i, min(len(ds), i + bs))])
+            feats, lab = batch["input_features"].to(dev), batch["labels"].to(dev)
+            out = self.model(input_features=feats, labels=lab)
+            n_tok = int((lab != -100).sum())
+            losses.append(float(out.loss) * n_tok); weights.append(n_tok)
+            if self.args.predict_with_generate:
+                preds.append(self.model.generate(feats, max_length=self.args.generation_max_length).cpu())
+                labels.append(lab.cpu())
+        metrics = {"eval_loss": sum(losses) / max(1, sum(weights))}
+        if self.args.predict_with_generate and self.compute_metrics is not None:
+            width = max(p.shape[1] for p in preds)
+            lw = max(l.shape[1] for l in labels)
+            pad = self.model.config.pad_token_id
+            pred = torch.cat([F.pad(p, (0, width - p.shape[1]), value=pad) for p in preds]).numpy()
+            lab = torch.cat([F.pad(l, (0, lw - l.shape[1]), value=-100) for l in labels]).numpy()
+            for k, v in self.compute_metrics(SimpleNamespace(predictions=pred, label_ids=lab)).items():
+                metrics[k if k.startswith("eval_") else "eval_" + k] = float(v)
+        self.model.train(was_training)
+        metrics["step"] = self.global_step
+        self.log_history.append(dict(metrics))
+        return metrics
+
     def train(self):
-        if self.args.predict_with_generate or self.args.report_to:
-            print("[finetune] note: generate-based evaluation / WER / wandb are outside the native hot path and are skipped")
+        if self.args.report_to:
+            print("[finetune] note: wandb / hub reporting is outside the native hot path and is skipped")
+        do_eval = self.args.evaluation_strategy == "steps" and self.eval_dataset is not None and self.args.eval_steps > 0
+        key = self.args.metric_for_best_model
+        key = key if key.startswith("eval_") else "eval_" + key
+        best, best_state = None, None
         it = self._batches()
         for _ in range(self.args.max_steps):
             loss = self.training_step(next(it))
             if self.global_step % max(1, self.args.logging_steps) == 0 or self.global_step == 1:
                 self.log_history.append({"step": self.global_step, "loss": loss, "lr": self.scheduler.get_last_lr()[0]})
+            if do_eval and self.global_step % self.args.eval_steps == 0:
+                m = self.evaluate()
+                score = m.get(key, m["eval_loss"])
+                better = best is None or (score > best if self.args.greater_is_better and key in m else score < best)
+                if better:
+                    best = score
+                    best_state = {k: v.detach().clone() for k, v in self.model.encoder.state_dict().items() if "lora_" in k}
             if self.args.save_steps and self.global_step % self.args.save_steps == 0:
                 self.save_model()
-        return SimpleNamespace(global_step=self.global_step, training_loss=self.log_history[-1]["loss"] if self.log_history else float("nan"))
+        if self.args.load_best_model_at_end and best_state is not None:      # fineTune.py:178-180
+            self.model.encoder.load_state_dict(best_state, strict=False)
+        train_losses = [h["loss"] for h in self.log_history if "loss" in h]
+        return SimpleNamespace(global_step=self.global_step, training_loss=train_losses[-1] if train_losses else float("nan"),
+                               best_metric=best)
 
     def save_model(self, output_dir: Optional[str] = None):
         """Adapter-only checkpoint (the frozen base is not rewritten): `<output_dir>/lora_adapters.pt`, HF-style keys."""

@@ -63,6 +63,40 @@ def unit_variates(name: str, count: int, seed: int = 0) -> np.ndarray:
     return out
 
 
+def decoder_param_shapes(d: int, layers: int, ffn: int, vocab: int, max_target_positions: int = 448) -> List[Tuple[str, Tuple[int, ...]]]:
+    """HF `WhisperDecoder.state_dict()` keys and shapes (HF:modeling_whisper.py:416-507,649-700)."""
+    shapes: List[Tuple[str, Tuple[int, ...]]] = [("embed_tokens.weight", (vocab, d)), ("embed_positions.weight", (max_target_positions, d))]
+    for i in range(layers):
+        p = f"layers.{i}."
+        for att in ("self_attn", "encoder_attn"):
+            shapes += [(p + att + ".k_proj.weight", (d, d)), (p + att + ".v_proj.weight", (d, d)), (p + att + ".v_proj.bias", (d,)),
+                       (p + att + ".q_proj.weight", (d, d)), (p + att + ".q_proj.bias", (d,)),
+                       (p + att + ".out_proj.weight", (d, d)), (p + att + ".out_proj.bias", (d,)),
+                       (p + att + "_layer_norm.weight", (d,)), (p + att + "_layer_norm.bias", (d,))]
+        shapes += [(p + "fc1.weight", (ffn, d)), (p + "fc1.bias", (ffn,)), (p + "fc2.weight", (d, ffn)), (p + "fc2.bias", (d,)),
+                   (p + "final_layer_norm.weight", (d,)), (p + "final_layer_norm.bias", (d,))]
+    return shapes + [("layer_norm.weight", (d,)), ("layer_norm.bias", (d,))]
+
+
+def init_decoder_weights(d: int, layers: int, ffn: int, vocab: int, max_target_positions: int = 448, seed: int = 0) -> Dict[str, np.ndarray]:
+    """Platform-independent fp32 decoder state dict (names prefixed "decoder." for the generator key): linears of std
+    d^-1/2 / 2, token embeddings of std 0.1, positions of std 0.5, non-trivial biases and LayerNorm affines, so that logits are far from uniform."""
+    out: Dict[str, np.ndarray] = {}
+    for name, shape in decoder_param_shapes(d, layers, ffn, vocab, max_target_positions):
+        n = int(np.prod(shape))
+        u = unit_variates("decoder." + name, n, seed)
+        if "layer_norm.weight" in name:
+            v = 1.0 + 0.1 * u
+        elif name.startswith("embed_"):
+            v = (0.5 if "positions" in name else 0.1) * u     # strong positions: greedy decoding does not collapse to one token
+        elif name.endswith(".weight"):
+            v = u * (0.5 / math.sqrt(shape[1]))
+        else:
+            v = 0.05 * u
+        out[name] = v.astype(np.float32).reshape(shape)
+    return out
+
+
 @dataclass(frozen=True)
 class EncoderConfig:
     """Shape of a Whisper-style audio encoder (HF `WhisperConfig` field names in comments)."""

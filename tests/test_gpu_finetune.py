@@ -37,7 +37,7 @@ def test_loss_decreases_and_checkpoint_roundtrip(tmp_path):
     tr = Seq2SeqTrainer(args=args, model=model, train_dataset=ds, eval_dataset=ds,
                         data_collator=DataCollatorSpeechSeq2SeqWithPadding(processor=None, decoder_start_token_id=50258), tokenizer=None)
     tr.train()
-    losses = [h["loss"] for h in tr.log_history]
+    losses = [h["loss"] for h in tr.log_history if "loss" in h]
     assert losses[-1] < losses[0] - 0.05, losses
     ck = torch.load(tmp_path / "lora_adapters.pt")
     assert set(ck["lora"]) == {k for k in model.encoder.state_dict() if "lora_" in k} and ck["r"] == 8
@@ -83,3 +83,59 @@ def test_native_cross_kv_projection_matches_torch_decoder():
     assert abs(out[True][0] - out[False][0]) < 2e-4 * abs(out[False][0])
     ref = out[False][1]
     assert float((out[True][1] - ref).abs().max()) < 2e-3 * float(ref.abs().max())
+
+
+def _golden_model():
+    """WhisperLoRAModel with the deterministic weights of tests/golden/decoder.npz (tools/make_golden.py gen_decoder)."""
+    from mlx8_ws_audio_transformer_amd.finetune import WhisperLoRAModel
+    cfg = wts.config("mini", True)
+    model = WhisperLoRAModel(cfg, wts.LoraSpec(r=8, alpha=16.0), decoder_layers=2, vocab=512, max_target_positions=64)
+    model.config.decoder_start_token_id, model.config.pad_token_id, model.config.eos_token_id = 1, 0, 2
+    We = wts.init_encoder_weights(cfg, seed=0, profile="test")
+    Wd = wts.init_decoder_weights(cfg.d_model, 2, cfg.ffn, 512, 64, seed=0)
+    model.encoder.load_state_dict({k: torch.from_numpy(v) for k, v in We.items()}, strict=False)      # LoRA B = 0: adapters are inert
+    model.decoder.load_state_dict({k: torch.from_numpy(v) for k, v in Wd.items()}, strict=True)
+    mel = oracle_mel.whisper_logmel(piano_clips_f32(2), n_samples=2 * cfg.max_source_positions * 160)
+    return model.eval(), torch.from_numpy(mel).cuda()
+
+
+def test_step_loss_logits_and_greedy_tokens_match_reference():
+    """fineTune.py's forward (a9: shift labels, encoder, decoder, tied projection, CE) and greedy decoding against
+    WhisperForConditionalGeneration on the same weights."""
+    from tests.util import golden
+    G = golden("decoder.npz")
+    model, mel = _golden_model()
+    with torch.no_grad():
+        out = model(input_features=mel, labels=torch.from_numpy(G["labels"]).cuda())
+    np.testing.assert_allclose(out.encoder_last_hidden_state[:, :4].cpu().numpy(), G["encoder_head"], rtol=0, atol=1e-3)
+    np.testing.assert_allclose(out.logits.float().cpu().numpy(), G["logits"], rtol=0, atol=2e-3)
+    assert abs(float(out.loss) - float(G["loss"])) < 1e-3
+    ids = model.generate(mel, max_length=G["greedy_ids"].shape[1]).cpu().numpy()
+    np.testing.assert_array_equal(ids, G["greedy_ids"])
+
+
+def test_evaluate_with_generate_and_wer():
+    from mlx8_ws_audio_transformer_amd.collator import DataCollatorSpeechSeq2SeqWithPadding
+    from mlx8_ws_audio_transformer_amd.finetune import Seq2SeqTrainer, Seq2SeqTrainingArguments, wer
+    from tests.util import golden
+    G = golden("decoder.npz")
+    model, mel = _golden_model()
+    greedy = G["greedy_ids"]
+    # labels = what the model itself decodes for clip 0, and a deliberately wrong sequence for clip 1
+    ds = [{"input_features": mel[0].cpu().numpy(), "labels": greedy[0, :8].tolist()},
+          {"input_features": mel[1].cpu().numpy(), "labels": [1, 5, 6, 7, 8, 9, 10, 11]}]
+
+    def decode(rows):
+        return [" ".join(str(t) for t in r if t not in (-100, 0, 1, 2)) for r in rows]
+
+    def compute_metrics(pred):                      # the body of fineTune.py:145-158 with a toy tokenizer
+        lab = np.where(pred.label_ids == -100, 0, pred.label_ids)
+        return {"wer": 100 * wer(decode(lab), decode(pred.predictions))}
+
+    args = Seq2SeqTrainingArguments(per_device_eval_batch_size=2, generation_max_length=8, predict_with_generate=True)
+    tr = Seq2SeqTrainer(args=args, model=model, eval_dataset=ds, compute_metrics=compute_metrics,
+                        data_collator=DataCollatorSpeechSeq2SeqWithPadding(processor=None, decoder_start_token_id=1))
+    m = tr.evaluate()
+    assert m["eval_loss"] > 0
+    # clip 0 is decoded exactly (0 errors of 7 words), clip 1 shares no word with its reference (7 errors of 7)
+    assert abs(m["eval_wer"] - 50.0) < 1e-6, m

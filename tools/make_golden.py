@@ -142,6 +142,51 @@ def gen_encoder(cases=ENCODER_CASES, fname="encoder.npz"):
     np.savez_compressed(os.path.join(GOLD, fname), **out)
 
 
+DEC = dict(layers=2, vocab=512, max_pos=64, start=1, pad=0, eos=2, max_len=12)
+
+
+def decoder_labels():
+    lab = (3 + (np.abs(wts.unit_variates("dec_labels", 2 * 7, 0)) * 1e6).astype(np.int64) % 500).reshape(2, 7)
+    lab[:, 0] = DEC["start"]          # the collator strips a leading BOS only when every row has it; keep it to exercise the shift
+    lab[1, 5:] = -100
+    return lab
+
+
+def gen_decoder():
+    """Fixture for the fineTune.py step (a9): WhisperForConditionalGeneration.forward loss / logits and greedy tokens on
+    deterministic weights -- pins finetune.WhisperDecoder / shift_tokens_right / the CE loss / generate to the reference."""
+    from transformers import WhisperConfig, WhisperForConditionalGeneration
+    cfg = wts.config("mini", True)
+    hc = WhisperConfig(vocab_size=DEC["vocab"], d_model=cfg.d_model, encoder_layers=cfg.layers, encoder_attention_heads=cfg.heads,
+                       encoder_ffn_dim=cfg.ffn, num_mel_bins=cfg.n_mels, max_source_positions=cfg.max_source_positions,
+                       decoder_layers=DEC["layers"], decoder_attention_heads=cfg.heads, decoder_ffn_dim=cfg.ffn,
+                       max_target_positions=DEC["max_pos"], decoder_start_token_id=DEC["start"], pad_token_id=DEC["pad"],
+                       eos_token_id=DEC["eos"], bos_token_id=DEC["start"], suppress_tokens=None, begin_suppress_tokens=None)
+    hc._attn_implementation = "eager"
+    model = WhisperForConditionalGeneration(hc).eval()
+    We = wts.init_encoder_weights(cfg, seed=0, profile="test")
+    Wd = wts.init_decoder_weights(cfg.d_model, DEC["layers"], cfg.ffn, DEC["vocab"], DEC["max_pos"], seed=0)
+    sd = {"model.encoder." + k: torch.from_numpy(v) for k, v in We.items()}
+    sd.update({"model.decoder." + k: torch.from_numpy(v) for k, v in Wd.items()})
+    sd["proj_out.weight"] = sd["model.decoder.embed_tokens.weight"]
+    missing, unexpected = model.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    mel = torch.from_numpy(encoder_mel(cfg, 2))
+    labels = torch.from_numpy(decoder_labels())
+    with torch.no_grad():
+        res = model(input_features=mel, labels=labels)
+        # greedy decoding by full re-evaluation of the reference forward (no generate() machinery, no cache)
+        ids = torch.full((2, 1), DEC["start"], dtype=torch.long)
+        enc = (res.encoder_last_hidden_state,)
+        while ids.shape[1] < DEC["max_len"]:
+            lg = model(encoder_outputs=enc, decoder_input_ids=ids).logits
+            ids = torch.cat([ids, lg[:, -1].argmax(-1, keepdim=True)], dim=1)
+    out = {"loss": np.float64(res.loss.item()), "logits": res.logits.numpy(), "labels": labels.numpy(),
+           "encoder_head": res.encoder_last_hidden_state.numpy()[:, :4], "greedy_ids": ids.numpy()}
+    np.savez_compressed(os.path.join(GOLD, "decoder.npz"), **out)
+    print("decoder fixture written: loss", out["loss"], "greedy", ids.tolist())
+
+
 def make_pad_tokenizer():
     """A tokenizer whose only used behaviour is `.pad` (right-pad with Whisper's pad id 50257 + attention mask)."""
     from tokenizers import Tokenizer
@@ -190,6 +235,8 @@ if __name__ == "__main__":
         gen_logmel()
     if "encoder" in what:
         gen_encoder()
+    if "decoder" in what:
+        gen_decoder()
     if "encoder_large" in what:
         gen_encoder(ENCODER_CASES_LARGE, "encoder_large.npz")
     if "collator" in what:
