@@ -164,6 +164,11 @@ int awt_op_attention(awt_ctx* c, const float* q, const float* k, const float* v,
                      int terms, void* workspace, size_t ws_bytes, void* stream);
 size_t awt_op_attention_workspace_bytes(int B, int H, int S);
 
+/* Process-wide tuning / test hooks (no effect on results).  key "gemm_tile": 0 = choose the GEMM block tile from the
+ * shape (default), 64 / 128 / 256 = force the 64 x 128, 128 x 128 or 128 x 256 tile (256 falls back to 128 when N is not
+ * a multiple of 256) so that tests can drive every tiling on small shapes. */
+int awt_tuning_set(const char* key, int value);
+
 /* ------------------------------------------------------------------------------------------------------
  * In-library kernel timing with HIP events on the caller's stream (bench.py's `roofline` leg).
  * awt_prof_enable(c, mask) makes every launch of the kernel classes whose bit (1 << AWT_PROF_x) is set in `mask`

@@ -61,6 +61,7 @@ _SIGNATURES = {
     "awt_op_layernorm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "awt_op_attention": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "awt_op_attention_workspace_bytes": (_sz, [_i, _i, _i]),
+    "awt_tuning_set": (_i, [C.c_char_p, _i]),
     "awt_prof_enable": (_i, [_vp, _i]),
     "awt_prof_collect": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(C.c_double)]),
 }
@@ -148,3 +149,8 @@ def prof_collect(klass: str):
     ms, n, fl = C.c_double(), _i64(), C.c_double()
     check(lib().awt_prof_collect(ctx(), PROF_CLASSES[klass], C.byref(ms), C.byref(n), C.byref(fl)))
     return ms.value, n.value, fl.value
+
+
+def tuning_set(key: str, value: int) -> None:
+    """Process-wide tuning / test hook (include/awt.h: awt_tuning_set), e.g. tuning_set("gemm_tile", 128)."""
+    check(lib().awt_tuning_set(key.encode(), int(value)))

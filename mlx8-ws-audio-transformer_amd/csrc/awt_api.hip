@@ -37,6 +37,16 @@ void awt_prof_end(awt_ctx* c, int klass, hipStream_t s) {
   p->spans[klass].push_back(p->open[klass]);
 }
 
+extern "C" int awt_tuning_set(const char* key, int value) {
+  AWT_REQUIRE(key, AWT_ERR_INVALID, "tuning_set: null key");
+  if (!strcmp(key, "gemm_tile")) {
+    AWT_REQUIRE(value == 0 || value == 64 || value == 128 || value == 256, AWT_ERR_INVALID, "tuning_set: gemm_tile must be 0 (auto), 64, 128 or 256");
+    awt_gemm_force_tile(value);
+    return AWT_OK;
+  }
+  AWT_REQUIRE(false, AWT_ERR_INVALID, "tuning_set: unknown key");
+}
+
 extern "C" int awt_prof_enable(awt_ctx* c, int on) {
   AWT_REQUIRE(c, AWT_ERR_INVALID, "prof_enable: null ctx");
   if (!c->prof) c->prof = new awt_prof_state();

@@ -156,7 +156,7 @@ int prepare_waveform_impl(awt_ctx* c, const void* pcm, int pcm_is_i16, int chann
                           int n_in, int sr_in, int sr_out, float* out, int n_out, hipStream_t s);
 int64_t resampled_length(int n_in, int sr_in, int sr_out);
 void awt_free_tables(awt_ctx* c);
-void awt_gemm_force_tile(int t);  // 0 auto, 128 or 256: tuning / tests
+void awt_gemm_force_tile(int t);  // 0 auto, 64 / 128 / 256: tuning / tests (awt_tuning_set)
 
 // ---- backward-pass launchers
 int launch_attention_bwd(awt_ctx* c, const bf16_t* q_hi, const bf16_t* q_lo, const bf16_t* k_hi, const bf16_t* k_lo,

@@ -40,6 +40,7 @@ struct GemmArgs {
 };
 
 // block-tile configurations: WM x WN waves, each wave TM x TN tiles of 16 x 16
+struct Cfg64 { static constexpr int WM = 2, WN = 2, TM = 2, TN = 4; };         // 64 x 128: small M (a few clips), where the chip is filled by tile count
 struct Cfg128 { static constexpr int WM = 2, WN = 2, TM = 4, TN = 4; };
 struct CfgW4 { static constexpr int WM = 1, WN = 4, TM = 8, TN = 4; };        // 128 x 256 on 4 waves: two independent workgroups per CU
 
@@ -221,7 +222,6 @@ __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, 2) void gemm_kernel(GemmArg
   using ST = Stager<TERMS, BK, CFG>;
   constexpr int TM = CFG::TM, TN = CFG::TN, KS = T::KS, STEPS = KS * TM, NOPS = T::NA + T::NB;
   constexpr int OPS_PER_STEP = (NOPS + STEPS - 1) / STEPS;
-  static_assert(TM == 4 || TM == 8, "steps are unrolled by hand");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, 2) void gemm_kernel(GemmArg
   }
 }
 
-int g_force_tile = 0;  // 0 = auto, 128 / 256 = forced (tuning and tests)
+int g_force_tile = 0;  // 0 = auto, 64 / 128 / 256 = forced (tuning and tests)
 // Tile order (see the kernel).  Measured on the encoder's shapes (tools/gemm_traffic_shapes.sh, profiles/r01_gemm_tile_order.txt):
 // column-tile groups of 3 cut the L2 -> fabric reads by 10 - 25 % but run 1.5 % slower end to end than groups of GM = 4 row
 // panels, so row-panel groups are the default; AWT_GEMM_GROUP_N=n selects column groups for experiments.
@@ -390,13 +390,20 @@ int launch_one(GemmArgs a, hipStream_t s) {
 }
 
 
-// Large shapes (every encoder GEMM at batch size >= 2) use 128 x 256 tiles on 4 waves, two workgroups per CU; the rest
-// (N = 128 LoRA projections, N = 384 models, tiny M) use 128 x 128.
+// Tile choice by tile count: a launch should put at least one tile on each of the 512 workgroup slots (256 CUs x 2) --
+// with fewer, its duration is one tile's K loop however small M is, so smaller tiles (shorter K-tile steps) win.
+//   128 x 256 (4 waves of 128 x 64): the encoder's shapes from ~3 clips up;  128 x 128: N not a multiple of 256 (LoRA
+//   projections, N = 384 models) and mid-sized M;  64 x 128: one or two clips (M = 1500 .. 3000) and tiny test shapes.
+constexpr int kSlots = 512;
 template <int EPI>
 int launch_epi(GemmArgs a, int terms, hipStream_t s) {
-  const bool big = g_force_tile ? g_force_tile == 256 : (a.N % 256 == 0 && a.M >= 2048);
-  if (!big) return terms == 3 ? launch_one<3, 32, EPI, Cfg128>(a, s) : launch_one<1, 64, EPI, Cfg128>(a, s);
-  return terms == 3 ? launch_one<3, 32, EPI, CfgW4>(a, s) : launch_one<1, 64, EPI, CfgW4>(a, s);
+  const int64_t t256 = (int64_t)((a.M + 127) / 128) * (a.N / 256), t128 = (int64_t)((a.M + 127) / 128) * (a.N / 128);
+  int tile = g_force_tile;
+  if (!tile) tile = (a.N % 256 == 0 && t256 >= kSlots) ? 256 : (t128 >= kSlots ? 128 : 64);
+  if (tile == 256 && a.N % 256 != 0) tile = 128;
+  if (tile == 256) return terms == 3 ? launch_one<3, 32, EPI, CfgW4>(a, s) : launch_one<1, 64, EPI, CfgW4>(a, s);
+  if (tile == 128) return terms == 3 ? launch_one<3, 32, EPI, Cfg128>(a, s) : launch_one<1, 64, EPI, Cfg128>(a, s);
+  return terms == 3 ? launch_one<3, 32, EPI, Cfg64>(a, s) : launch_one<1, 64, EPI, Cfg64>(a, s);
 }
 
 bf16_t* g_zeros = nullptr;

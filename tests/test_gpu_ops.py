@@ -15,16 +15,29 @@ def _rand(shape, seed, scale=1.0):
 TOL = {"bf16x3": 2e-5, "bf16": 1.5e-2}
 
 
+@pytest.mark.parametrize("tile", [0, 64, 128, 256])                    # 0 = chosen from the shape; the others force each block tiling
 @pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 256, 192), (1500, 384, 768), (77, 128, 3072),
-                                   (2500, 768, 768), (4096, 256, 128), (3000, 2304, 768)])  # last three: 128 x 256 (4-wave) tile path
-def test_linear(precision, M, N, K):
-    from mlx8_ws_audio_transformer_amd import ops
+                                   (2500, 768, 768), (4096, 256, 128), (3000, 2304, 768)])
+def test_linear(precision, M, N, K, tile):
+    from mlx8_ws_audio_transformer_amd import _lib, ops
     x, w, b = _rand((M, K), 1), _rand((N, K), 2, K ** -0.5), _rand((N,), 3)
-    y = ops.linear(x, w, b, precision)
+    _lib.tuning_set("gemm_tile", tile)
+    try:
+        y = ops.linear(x, w, b, precision)
+    finally:
+        _lib.tuning_set("gemm_tile", 0)
     ref = torch.nn.functional.linear(x.double(), w.double(), b.double())
     err = (y.double() - ref).abs().max().item()
     assert err < TOL[precision] * max(1.0, ref.abs().max().item()), err
+
+
+def test_tuning_set_rejects_unknown():
+    from mlx8_ws_audio_transformer_amd import _lib
+    with pytest.raises(_lib.AwtError):
+        _lib.tuning_set("gemm_tile", 100)
+    with pytest.raises(_lib.AwtError):
+        _lib.tuning_set("no_such_key", 1)
 
 
 def test_linear_identity_with_asymmetric_weight():
