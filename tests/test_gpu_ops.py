@@ -81,3 +81,14 @@ def test_attention_online_softmax_rescale_branch():
     p = torch.softmax(q.double() @ k.double().transpose(2, 3), dim=-1)
     ref = (p @ v.double()).transpose(1, 2).reshape(B, S, 64)
     assert (o.double() - ref).abs().max().item() < 3e-4  # logits reach ~170: fp32 ulp of the exp2 argument is ~1.5e-5
+
+
+def test_linear_output_larger_than_2g_elements():
+    """M x N > 2^31 output elements (the fused decoder cross-attention projection is 96000 x 18432): 64-bit addressing."""
+    from mlx8_ws_audio_transformer_amd import ops
+    M, N, K = 96000, 24576, 128
+    x, w, b = _rand((M, K), 11), _rand((N, K), 12, K ** -0.5), _rand((N,), 13)
+    y = ops.linear(x, w, b, "bf16x3")
+    rows = torch.tensor([0, 1, 47999, 87380, 87382, M - 1], device="cuda")       # 87381 * 24576 ~ 2^31
+    ref = torch.nn.functional.linear(x[rows].double(), w.double(), b.double())
+    assert (y[rows].double() - ref).abs().max().item() < TOL["bf16x3"] * max(1.0, ref.abs().max().item())
