@@ -303,11 +303,7 @@ __global__ __launch_bounds__(kThreads, 2) void attention_kernel(AttnArgs a) {
 template <int TERMS>
 int launch_t(const AttnArgs& a, hipStream_t s) {
   constexpr int lds = 2 * (TERMS == 3 ? 4 : 2) * PLANE;
-  static bool attr = false;
-  if (!attr) {
-    AWT_HIP_CHECK(hipFuncSetAttribute((const void*)attention_kernel<TERMS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    attr = true;
-  }
+  AWT_ONCE_PER_DEVICE(AWT_HIP_CHECK(hipFuncSetAttribute((const void*)attention_kernel<TERMS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)));
   dim3 grid(((a.S + QB - 1) / QB) * a.B * a.H);
   hipLaunchKernelGGL(attention_kernel<TERMS>, grid, dim3(kThreads), lds, s, a);
   AWT_HIP_CHECK(hipGetLastError());

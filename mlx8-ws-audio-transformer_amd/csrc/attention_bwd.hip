@@ -281,11 +281,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* do_hi, co
 template <int TERMS, int MODE>
 int launch_mode(const BwdArgs& a, hipStream_t s) {
   constexpr int lds = 2 * ((TERMS == 3 ? 4 : 2) * PLANE + 512);
-  static bool attr = false;
-  if (!attr) {
-    AWT_HIP_CHECK(hipFuncSetAttribute((const void*)attention_bwd_kernel<TERMS, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    attr = true;
-  }
+  AWT_ONCE_PER_DEVICE(AWT_HIP_CHECK(hipFuncSetAttribute((const void*)attention_bwd_kernel<TERMS, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)));
   dim3 grid(((a.S + LB - 1) / LB) * a.B * a.H);
   hipLaunchKernelGGL((attention_bwd_kernel<TERMS, MODE>), grid, dim3(kThreads), lds, s, a);
   AWT_HIP_CHECK(hipGetLastError());

@@ -85,12 +85,17 @@ extern "C" int awt_ctx_create(int device, awt_ctx** out) {
               std::string("libawt is built for gfx950 (MI355X) only; device is ") + prop.gcnArchName);
   awt_ctx* c = new awt_ctx();
   c->device = device;
+  if (hipMalloc(&c->zeros, 256) != hipSuccess || hipMemset(c->zeros, 0, 256) != hipSuccess) {
+    delete c;
+    AWT_REQUIRE(false, AWT_ERR_HIP, "ctx_create: could not allocate the zero page");
+  }
   *out = c;
   return AWT_OK;
 }
 extern "C" void awt_ctx_destroy(awt_ctx* c) {
   if (!c) return;
   awt_free_tables(c);
+  if (c->zeros) (void)hipFree(c->zeros);
   if (c->prof) {
     for (int k = 0; k < AWT_PROF_NCLASSES; ++k)
       for (auto& sp : c->prof->spans[k]) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }

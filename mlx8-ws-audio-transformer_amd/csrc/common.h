@@ -81,7 +81,20 @@ struct awt_ctx {
   // device-resident constant tables owned by the library, keyed by their parameters
   struct Table;
   Table* tables = nullptr;
+  void* zeros = nullptr;   // 256 zero bytes on this device (padding rows of the conv stem's implicit GEMM)
 };
+
+// hipFuncSetAttribute is per (function, device): run `set` once per device of this process for the calling site
+#define AWT_ONCE_PER_DEVICE(set)                                   \
+  do {                                                             \
+    static unsigned long long _done = 0;                           \
+    int _dev = 0;                                                  \
+    AWT_HIP_CHECK(hipGetDevice(&_dev));                            \
+    if (!((_done >> (_dev & 63)) & 1ull)) {                        \
+      set;                                                         \
+      _done |= 1ull << (_dev & 63);                                \
+    }                                                              \
+  } while (0)
 
 void awt_prof_begin(awt_ctx* c, int klass, hipStream_t s, double flops);
 void awt_prof_end(awt_ctx* c, int klass, hipStream_t s);

@@ -376,11 +376,7 @@ int g_group_n = 0;
 template <int TERMS, int BK, int EPI, class CFG>
 int launch_one(GemmArgs a, hipStream_t s) {
   using T = Tile<TERMS, BK, CFG>;
-  static bool attr = false;
-  if (!attr) {
-    AWT_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_kernel<TERMS, BK, EPI, CFG>, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
-    attr = true;
-  }
+  AWT_ONCE_PER_DEVICE(AWT_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_kernel<TERMS, BK, EPI, CFG>, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES)));
   a.tiles_m = (a.M + T::BM - 1) / T::BM;
   a.tiles_n = (a.N + T::BN - 1) / T::BN;
   a.group_n = g_group_n;
@@ -406,7 +402,6 @@ int launch_epi(GemmArgs a, int terms, hipStream_t s) {
   return terms == 3 ? launch_one<3, 32, EPI, Cfg64>(a, s) : launch_one<1, 64, EPI, Cfg64>(a, s);
 }
 
-bf16_t* g_zeros = nullptr;
 
 }  // namespace
 
@@ -417,13 +412,11 @@ int launch_gemm(awt_ctx* c, int M, int N, const GemmSeg* segs, int nseg, int ter
   AWT_REQUIRE(M > 0 && N > 0 && N % 128 == 0, AWT_ERR_INVALID, "gemm: N must be a positive multiple of 128");
   AWT_REQUIRE(nseg >= 1 && nseg <= kMaxSeg, AWT_ERR_INVALID, "gemm: 1..3 K-segments");
   AWT_REQUIRE(terms == 1 || terms == 3, AWT_ERR_INVALID, "gemm: terms must be 1 or 3");
-  if (!g_zeros) {
-    if (const char* e = getenv("AWT_GEMM_GROUP_N")) g_group_n = std::max(0, atoi(e));   // tile-order experiments (tools/)
-    AWT_HIP_CHECK(hipMalloc((void**)&g_zeros, 256));
-    AWT_HIP_CHECK(hipMemset(g_zeros, 0, 256));
-  }
+  AWT_REQUIRE(c && c->zeros, AWT_ERR_INVALID, "gemm: context without a zero page");
+  static const bool env_read = [] { if (const char* e = getenv("AWT_GEMM_GROUP_N")) g_group_n = std::max(0, atoi(e)); return true; }();   // tile-order experiments (tools/)
+  (void)env_read;
   GemmArgs a{};
-  a.M = M; a.N = N; a.nseg = nseg; a.out = out; a.zeros = g_zeros;
+  a.M = M; a.N = N; a.nseg = nseg; a.out = out; a.zeros = (const bf16_t*)c->zeros;
   double ksum = 0;
   for (int i = 0; i < nseg; ++i) {
     a.seg[i] = segs[i];

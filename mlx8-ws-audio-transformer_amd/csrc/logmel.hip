@@ -314,11 +314,7 @@ int launch_stage1(const LogmelParams& p, int B, int max_live, hipStream_t s) {
   const int span_pad = span + span / p.hop + 1;
   const size_t lds = (((size_t)span_pad * 4 + 15) & ~(size_t)15) + (size_t)FT * p.nbp * 8;
   AWT_REQUIRE(lds <= 160 * 1024, AWT_ERR_INVALID, "logmel: frame tile does not fit LDS");
-  static bool attr_set[3] = {false, false, false};
-  if (!attr_set[FTILES]) {
-    AWT_HIP_CHECK(hipFuncSetAttribute((const void*)logmel_stage1_kernel<FTILES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set[FTILES] = true;
-  }
+  AWT_ONCE_PER_DEVICE(AWT_HIP_CHECK(hipFuncSetAttribute((const void*)logmel_stage1_kernel<FTILES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
   dim3 grid((max_live + FT - 1) / FT, B);
   if (grid.x == 0) return AWT_OK;
   hipLaunchKernelGGL(logmel_stage1_kernel<FTILES>, grid, dim3(kThreads), lds, s, p);
