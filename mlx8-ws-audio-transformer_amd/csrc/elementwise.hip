@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void pack_weight_t_kernel(const float* __restr
 // each thread owns 4 consecutive Y columns and r x 4 accumulators.  A second kernel sums the slabs in a fixed order,
 // so the gradients are bit-reproducible run to run.
 constexpr int kOrRows = 256;
-constexpr int kOrMaxBlocks = 128;   // workgroups walk the 256-row slabs grid-strided, so the second pass sums <= 128 partials
+constexpr int kOrMaxBlocks = 512;   // workgroups walk the 256-row slabs grid-strided, so the second pass sums <= 512 partials
 template <int R>
 __global__ __launch_bounds__(256) void outer_reduce_kernel(const bf16_t* x_hi, const bf16_t* x_lo, int64_t ldx, int xcol,
                                                            const bf16_t* y_hi, const bf16_t* y_lo, int64_t ldy, int ycol, int ny, int M,
@@ -252,22 +252,30 @@ __global__ __launch_bounds__(256) void outer_reduce_kernel(const bf16_t* x_hi, c
     }
     __syncthreads();
     if (n < ny) {
-      for (int mm = 0; mm < rows; ++mm) {
+      auto load_y = [&](int mm, float (&y)[4]) {
         const int64_t o = (int64_t)(m0 + mm) * ldy + ycol + n;
         const uint2 yh = *reinterpret_cast<const uint2*>(y_hi + o);
         uint2 yl = make_uint2(0u, 0u);
         if (y_lo) yl = *reinterpret_cast<const uint2*>(y_lo + o);
-        float y[4];
         y[0] = bf16_to_f32((bf16_t)(yh.x & 0xFFFF)) + bf16_to_f32((bf16_t)(yl.x & 0xFFFF));
         y[1] = bf16_to_f32((bf16_t)(yh.x >> 16)) + bf16_to_f32((bf16_t)(yl.x >> 16));
         y[2] = bf16_to_f32((bf16_t)(yh.y & 0xFFFF)) + bf16_to_f32((bf16_t)(yl.y & 0xFFFF));
         y[3] = bf16_to_f32((bf16_t)(yh.y >> 16)) + bf16_to_f32((bf16_t)(yl.y >> 16));
+      };
+      auto fma_row = [&](int mm, const float (&y)[4]) {
 #pragma unroll
         for (int j = 0; j < R; ++j) {
           const float xv = xs[mm][j];
           acc[j][0] += xv * y[0]; acc[j][1] += xv * y[1]; acc[j][2] += xv * y[2]; acc[j][3] += xv * y[3];
         }
+      };
+      int mm = 0;
+      for (; mm + 4 <= rows; mm += 4) {       // four rows of Y in flight per thread: the loop is bound by HBM latency, not FMAs
+        float y0[4], y1[4], y2[4], y3[4];
+        load_y(mm, y0); load_y(mm + 1, y1); load_y(mm + 2, y2); load_y(mm + 3, y3);
+        fma_row(mm, y0); fma_row(mm + 1, y1); fma_row(mm + 2, y2); fma_row(mm + 3, y3);   // row order kept: the sum is reproducible
       }
+      for (; mm < rows; ++mm) { float y[4]; load_y(mm, y); fma_row(mm, y); }
     }
   }
   if (n < ny) {
