@@ -6,6 +6,8 @@
   computed by libawt's `awt_logmel_generic` (periodic Hann, center / reflect, power 2, HTK mel, no norm);
 * `prepare_waveform` = mono mean + `Resample(sr -> SAMPLE_RATE)` + pad / trim to DURATION (spectrogram.py:145-157);
   libawt's `awt_prepare_waveform` whenever the clip is on the GPU or needs resampling;
+* `read_wav` + `preprocess_to_parquet` = the preprocessing loop (spectrogram.py:120-182): WAV samples go to the GPU as
+  they lie in the file, one `awt_prepare_waveform` launch per file, one `awt_logmel_generic` launch per batch of files;
 * `UrbanSoundDataSet(parquet_path=None, folds=None)` with `.df`, `.n_mels`, `__len__`, `__getitem__ ->
   (FloatTensor[n_mels, T], int)` over the reference's Parquet schema `rel_path, fold, class_id, class_name,
   log_mel_flat, log_mel_shape` (spectrogram.py:166-173,184-212).
@@ -29,6 +31,8 @@ FMIN = int(os.getenv("FMIN", 0))
 FMAX = int(os.getenv("FMAX", 8000))
 DURATION = float(os.getenv("DURATION", 4.0))
 PROCESSED_PARQUET_PATH = os.getenv("PROCESSED_PARQUET_PATH", "./.data/UrbanSound8K/processed")
+DATA_ROOT = os.getenv("DATA_ROOT", "./.data/UrbanSound8K")
+METADATA_CSV = os.getenv("METADATA_CSV", "./.data/UrbanSound8K/metadata/UrbanSound8K.csv")
 
 
 def get_processed_parquet_filename(n_mels: int = None, hop: int = None) -> str:
@@ -117,9 +121,106 @@ def record_for_parquet(rel_path: str, fold: int, class_id: int, class_name: str,
             "log_mel_flat": a.flatten(), "log_mel_shape": list(a.shape)}
 
 
+def read_wav(path: str):
+    """RIFF/WAVE reader for what UrbanSound8K ships as plain samples: integer PCM of 8 / 16 / 24 / 32 bits and IEEE float
+    32 / 64 (format tags 1, 3 and their WAVE_FORMAT_EXTENSIBLE forms).  Returns (samples [n, C] in file order, rate):
+    int16 for 16-bit PCM (the GPU scales it by 1/32768 like torchaudio.load), float32 in [-1, 1) otherwise.
+    Compressed formats (ADPCM, ...) raise ValueError; the preprocessing loop logs and skips such files as the
+    reference does with any loader error (spectrogram.py:174-175)."""
+    import struct
+
+    with open(path, "rb") as f:
+        data = f.read()
+    if len(data) < 12 or data[:4] != b"RIFF" or data[8:12] != b"WAVE":
+        raise ValueError(f"{path}: not a RIFF/WAVE file")
+    pos, fmt, pcm = 12, None, None
+    while pos + 8 <= len(data):
+        tag, size = data[pos: pos + 4], struct.unpack("<I", data[pos + 4: pos + 8])[0]
+        body = data[pos + 8: pos + 8 + size]
+        if tag == b"fmt ":
+            fmt = body
+        elif tag == b"data":
+            pcm = body
+        pos += 8 + size + (size & 1)
+    if fmt is None or pcm is None or len(fmt) < 16:
+        raise ValueError(f"{path}: missing fmt or data chunk")
+    code, channels, rate, _, align, bits = struct.unpack("<HHIIHH", fmt[:16])
+    if code == 0xFFFE and len(fmt) >= 26:                      # WAVE_FORMAT_EXTENSIBLE: the sub-format GUID starts with the real tag
+        code = struct.unpack("<H", fmt[24:26])[0]
+    if channels < 1 or align != channels * bits // 8:
+        raise ValueError(f"{path}: inconsistent fmt chunk")
+    n = len(pcm) // align
+    raw = np.frombuffer(pcm, dtype=np.uint8, count=n * align)
+    if code == 1 and bits == 16:
+        x = raw.view("<i2").reshape(n, channels).copy()
+    elif code == 1 and bits == 8:
+        x = ((raw.astype(np.float32) - 128.0) / 128.0).reshape(n, channels)
+    elif code == 1 and bits == 24:
+        b = raw.reshape(n * channels, 3).astype(np.int32)
+        v = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
+        v = np.where(v >= 1 << 23, v - (1 << 24), v)
+        x = (v.astype(np.float32) / float(1 << 23)).reshape(n, channels)
+    elif code == 1 and bits == 32:
+        x = (raw.view("<i4").astype(np.float64) / float(1 << 31)).astype(np.float32).reshape(n, channels)
+    elif code == 3 and bits in (32, 64):
+        x = raw.view("<f4" if bits == 32 else "<f8").astype(np.float32).reshape(n, channels)
+    else:
+        raise ValueError(f"{path}: unsupported WAVE format tag {code} with {bits} bits")
+    return torch.from_numpy(x), int(rate)
+
+
+def preprocess_to_parquet(metadata_csv: Optional[str] = None, data_root: Optional[str] = None, parquet_path: Optional[str] = None,
+                          overwrite: bool = False, loader=None, batch_files: int = 64, device: str = "cuda") -> Optional[str]:
+    """UrbanSound8K audio -> log-mel spectrograms -> Parquet, as spectrogram.py:120-182 (same columns, same row order).
+
+    `loader(path) -> (samples, rate)` defaults to `read_wav` ([n, C] file order); a torchaudio-style loader returning
+    [C, n] float tensors works too (`interleaved` is inferred from which axis is longer than 8).  Instead of prompting
+    on an existing file the function returns None unless `overwrite=True`."""
+    import pandas as pd
+    import pyarrow.parquet  # noqa: F401  (the Parquet engine pandas uses; imported here so a broken install fails with its own message)
+
+    parquet_path = parquet_path or get_processed_parquet_path()
+    if os.path.exists(parquet_path) and not overwrite:
+        return None
+    data_root = data_root or DATA_ROOT
+    df = pd.read_csv(metadata_csv or METADATA_CSV)
+    loader = loader or read_wav
+    n_out = int(SAMPLE_RATE * DURATION)
+    records, pending, meta = [], [], []
+
+    def flush():
+        if not pending:
+            return
+        mels = mel_spectrogram_log(torch.cat(pending, dim=0))          # one launch for the whole batch of files
+        for m, (rel_path, fold, class_id, class_name) in zip(mels, meta):
+            records.append(record_for_parquet(rel_path, fold, class_id, class_name, m))
+        pending.clear(); meta.clear()
+
+    for _, row in df.iterrows():
+        rel_path = os.path.join("audio", f"fold{row['fold']}", row["slice_file_name"])
+        try:
+            samples, rate = loader(os.path.join(data_root, rel_path))
+            interleaved = samples.dim() == 2 and samples.shape[1] <= 8 < samples.shape[0]
+            w = prepare_waveform(samples.to(device), sample_rate=rate, interleaved=interleaved)
+            assert tuple(w.shape) == (1, n_out)
+        except Exception as e:   # the reference logs and continues (spectrogram.py:174-175)
+            print(f"[urbansound] error processing {rel_path}: {e}")
+            continue
+        pending.append(w)
+        meta.append((rel_path, int(row["fold"]), int(row["classID"]), row["class"]))
+        if len(pending) >= batch_files:
+            flush()
+    flush()
+    out_df = pd.DataFrame(records)
+    os.makedirs(os.path.dirname(os.path.abspath(parquet_path)), exist_ok=True)
+    out_df.to_parquet(parquet_path, index=False)
+    return parquet_path
+
+
 class UrbanSoundDataSet(Dataset):
     def __init__(self, parquet_path: Optional[str] = None, folds=None):
         import pandas as pd
+        import pyarrow.parquet  # noqa: F401  (see preprocess_to_parquet)
 
         if parquet_path is None:
             parquet_path = get_processed_parquet_path()

@@ -60,3 +60,41 @@ def test_bad_arguments_raise():
         urbansound.prepare_waveform(torch.zeros(1, 100), sample_rate=500)
     with pytest.raises(_lib.AwtError):
         urbansound.prepare_waveform(torch.zeros(9, 100), sample_rate=44100)
+
+
+def test_preprocess_to_parquet_roundtrip(tmp_path):
+    """spectrogram.py:120-182 end to end: WAV files of mixed rate / width / channels -> Parquet -> UrbanSoundDataSet."""
+    import struct
+    import wave
+
+    import pandas as pd
+
+    root = tmp_path / "UrbanSound8K"
+    (root / "audio" / "fold1").mkdir(parents=True)
+    (root / "audio" / "fold2").mkdir(parents=True)
+    clips = {"a.wav": (44100, _clip(44100, 2.5, 2, 1)), "b.wav": (8000, _clip(8000, 1.0, 1, 2)), "c.wav": (16000, _clip(16000, 5.0, 1, 3))}
+    refs = {}
+    for name, (sr, x) in clips.items():
+        i16 = np.round(x * 20000).astype(np.int16)
+        with wave.open(str(root / "audio" / ("fold2" if name == "c.wav" else "fold1") / name), "wb") as w:
+            w.setnchannels(i16.shape[0]); w.setsampwidth(2); w.setframerate(sr)
+            w.writeframes(np.ascontiguousarray(i16.T).tobytes())
+        refs[name] = oracle_logmel.urbansound_logmel(R.prepare_waveform(i16.astype(np.float32) / 32768.0, sr), n_mels=urbansound.N_MELS,
+                                                     hop=urbansound.HOP_LENGTH)
+    (root / "audio" / "fold1" / "broken.wav").write_bytes(b"RIFF....WAVEjunk")
+    meta = pd.DataFrame({"slice_file_name": ["a.wav", "broken.wav", "b.wav", "c.wav"], "fold": [1, 1, 1, 2], "classID": [3, 0, 7, 9],
+                         "class": ["dog_bark", "x", "jackhammer", "street_music"]})
+    meta.to_csv(tmp_path / "meta.csv", index=False)
+    out = urbansound.preprocess_to_parquet(str(tmp_path / "meta.csv"), str(root), str(tmp_path / "out" / "p.parquet"), batch_files=2)
+    assert out and urbansound.preprocess_to_parquet(str(tmp_path / "meta.csv"), str(root), out) is None      # exists: not overwritten
+    ds = urbansound.UrbanSoundDataSet(out)
+    assert len(ds) == 3 and list(ds.df["class_id"]) == [3, 7, 9]                                            # the broken file is skipped
+    assert list(ds.df.columns) == ["rel_path", "fold", "class_id", "class_name", "log_mel_flat", "log_mel_shape"]
+    for i, name in enumerate(["a.wav", "b.wav", "c.wav"]):
+        mel, label = ds[i]
+        assert tuple(mel.shape) == refs[name].shape
+        # b.wav is UP-sampled: its mel bins above 4 kHz hold only the resampler's stop-band residue (power ~1e-9 next to the
+        # 1e-6 inside the log), where fp32-vs-float64 rounding of the filter sum moves ln(p + 1e-6) by ~1e-3
+        err = np.abs(mel.numpy() - refs[name]).max()
+        assert err < (5e-3 if name == "b.wav" else 2e-4), (name, err)
+    assert len(urbansound.UrbanSoundDataSet(out, folds=[2])) == 1
