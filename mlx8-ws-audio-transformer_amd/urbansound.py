@@ -45,14 +45,14 @@ def get_processed_parquet_path() -> str:
 
 
 def prepare_waveform(waveform: torch.Tensor, sample_rate: int = SAMPLE_RATE, duration: float = DURATION,
-                     target_rate: int = SAMPLE_RATE, interleaved: bool = False) -> torch.Tensor:
+                     target_rate: int = SAMPLE_RATE, interleaved: bool = False, n_out: Optional[int] = None) -> torch.Tensor:
     """[C, n] or [n] at `sample_rate` -> [1, int(target_rate * duration)] fp32: channel mean, resample to `target_rate`
     (torchaudio.transforms.Resample defaults), zero-pad or truncate (spectrogram.py:145-157, in that order).
 
     A CPU tensor already at the target rate takes the reference's three host tensor ops.  Anything else -- a device
     tensor (int16 or float32; `interleaved=True` for WAV-order [n, C] data) or a clip that needs resampling -- goes
     through libawt (`awt_prepare_waveform`) and comes back as a device tensor; there is no host resampler."""
-    n_out = int(target_rate * duration)
+    n_out = int(target_rate * duration) if n_out is None else int(n_out)
     w = waveform
     if not w.is_cuda and int(sample_rate) == int(target_rate) and not interleaved:
         w = w.float()
@@ -84,6 +84,17 @@ def prepare_waveform(waveform: torch.Tensor, sample_rate: int = SAMPLE_RATE, dur
                                                    sstride, n_in, int(sample_rate), int(target_rate), _lib.ptr(out), n_out,
                                                    _lib.stream_handle()))
     return out
+
+
+def preprocess_audio_for_cnn(waveform: torch.Tensor, sr: int):
+    """spectrogram.py:214-240: ([C, n] waveform, sr) -> (mono waveform at SAMPLE_RATE in full length, its DURATION-second
+    pad / trim, SAMPLE_RATE)."""
+    n_in = waveform.shape[-1]
+    n_full = n_in if int(sr) == SAMPLE_RATE else resampled_length(n_in, sr)
+    full = prepare_waveform(waveform, sample_rate=sr, n_out=n_full)
+    n = int(SAMPLE_RATE * DURATION)
+    cnn = torch.nn.functional.pad(full, (0, n - n_full)) if n_full < n else full[:, :n].clone()
+    return full, cnn, SAMPLE_RATE
 
 
 def resampled_length(n_in: int, sample_rate: int, target_rate: int = SAMPLE_RATE) -> int:

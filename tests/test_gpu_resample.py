@@ -54,6 +54,17 @@ def test_equal_rate_device_path_is_exact_and_feeds_logmel():
     np.testing.assert_allclose(mel, ref, rtol=0, atol=2e-4)   # resampler fp32 rounding (2e-6) through ln(power + 1e-6)
 
 
+def test_preprocess_audio_for_cnn_returns_full_and_fixed_length():
+    x = _clip(22050, 5.5, 2, seed=9)
+    full, cnn, sr = urbansound.preprocess_audio_for_cnn(torch.from_numpy(x), 22050)
+    ref = R.resample(x.mean(axis=0, dtype=np.float32), 22050, 16000)
+    assert sr == 16000 and tuple(full.shape) == (1, len(ref)) and tuple(cnn.shape) == (1, 64000)
+    np.testing.assert_allclose(full[0].cpu().numpy(), ref, rtol=0, atol=TOL)
+    np.testing.assert_array_equal(cnn.cpu().numpy(), full[:, :64000].cpu().numpy())
+    full, cnn, _ = urbansound.preprocess_audio_for_cnn(torch.from_numpy(_clip(16000, 1.0, 1, seed=10)), 16000)
+    assert tuple(full.shape) == (1, 16000) and tuple(cnn.shape) == (1, 64000) and not cnn[:, 16000:].any()
+
+
 def test_bad_arguments_raise():
     from mlx8_ws_audio_transformer_amd import _lib
     with pytest.raises(_lib.AwtError):
