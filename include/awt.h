@@ -62,6 +62,11 @@ size_t awt_logmel_workspace_bytes(int B);
 int awt_logmel_whisper(awt_ctx* c, const void* pcm, int pcm_is_i16, int64_t pcm_stride, const int32_t* n_valid,
                        int max_valid, int B, int n_frames_out, float* out, void* workspace, size_t ws_bytes,
                        void* stream);
+/* Same with the number of mel bins explicit: 80 (`WhisperFeatureExtractor()` defaults, tiny .. large-v2) or 128
+ * (`feature_size=128`, large-v3); out is [B, n_mels, n_frames_out]. */
+int awt_logmel_whisper_mels(awt_ctx* c, const void* pcm, int pcm_is_i16, int64_t pcm_stride, const int32_t* n_valid,
+                            int max_valid, int B, int n_frames_out, int n_mels, float* out, void* workspace, size_t ws_bytes,
+                            void* stream);
 
 /* UrbanSound log-mel (K15).  Stands behind `torch.log(mel_spectrogram(waveform) + 1e-6)`:
  *   /root/reference/.charles/spectrogram.py:79-87,160-162 (torchaudio MelSpectrogram: periodic Hann(n_fft),

@@ -42,6 +42,7 @@ _SIGNATURES = {
     "awt_ctx_destroy": (None, [_vp]),
     "awt_logmel_workspace_bytes": (_sz, [_i]),
     "awt_logmel_whisper": (_i, [_vp, _vp, _i, _i64, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "awt_logmel_whisper_mels": (_i, [_vp, _vp, _i, _i64, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "awt_logmel_generic": (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _f, _f, _f, _vp, _vp]),
     "awt_resampled_length": (_i64, [_i, _i, _i]),
     "awt_prepare_waveform": (_i, [_vp, _vp, _i, _i, _i64, _i64, _i, _i, _i, _vp, _i, _vp]),

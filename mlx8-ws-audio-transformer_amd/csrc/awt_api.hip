@@ -108,7 +108,13 @@ extern "C" void awt_ctx_destroy(awt_ctx* c) {
 extern "C" int awt_logmel_whisper(awt_ctx* c, const void* pcm, int pcm_is_i16, int64_t pcm_stride, const int32_t* n_valid,
                                   int max_valid, int B, int n_frames_out, float* out, void* workspace, size_t ws_bytes,
                                   void* stream) {
-  return logmel_whisper_impl(c, pcm, pcm_is_i16, pcm_stride, n_valid, max_valid, B, n_frames_out, out, workspace, ws_bytes,
+  return logmel_whisper_impl(c, pcm, pcm_is_i16, pcm_stride, n_valid, max_valid, B, n_frames_out, 80, out, workspace, ws_bytes,
+                             (hipStream_t)stream);
+}
+extern "C" int awt_logmel_whisper_mels(awt_ctx* c, const void* pcm, int pcm_is_i16, int64_t pcm_stride, const int32_t* n_valid,
+                                       int max_valid, int B, int n_frames_out, int n_mels, float* out, void* workspace, size_t ws_bytes,
+                                       void* stream) {
+  return logmel_whisper_impl(c, pcm, pcm_is_i16, pcm_stride, n_valid, max_valid, B, n_frames_out, n_mels, out, workspace, ws_bytes,
                              (hipStream_t)stream);
 }
 extern "C" int awt_logmel_generic(awt_ctx* c, const float* pcm, int64_t pcm_stride, int B, int n_samples, int sample_rate,
@@ -152,7 +158,8 @@ struct Layer {
   LoraGroup lq, lo_, l1, l2;
 };
 
-constexpr int kConv1K = 256;  // 3 taps x 80 mel bins = 240, zero-padded to a multiple of 64
+// conv1 as a GEMM: K = 3 taps x n_mels, zero-padded to a multiple of 64 (80 mels: 256, 128 mels: 384)
+int conv1_k(int n_mels) { return (3 * n_mels + 63) / 64 * 64; }
 constexpr size_t kAlign = 256;
 size_t align_up(size_t x) { return (x + kAlign - 1) & ~(kAlign - 1); }
 
@@ -224,7 +231,7 @@ Workspace carve(const awt_encoder* e, char* base, int Bc) {
   for (size_t p = 0; p < P; ++p) w.ff[p] = (bf16_t*)take(M * f * 2);
   const size_t layer_end = off;
   off = layer_start;
-  for (size_t p = 0; p < P; ++p) w.a1[p] = (bf16_t*)take(Mt * kConv1K * 2);
+  for (size_t p = 0; p < P; ++p) w.a1[p] = (bf16_t*)take(Mt * conv1_k(c.n_mels) * 2);
   for (size_t p = 0; p < P; ++p) w.h1[p] = (bf16_t*)take(Mt * d * 2);
   w.bytes = std::max(off, layer_end);
   return w;
@@ -301,7 +308,7 @@ TrainWs carve_train(const awt_encoder* e, char* base, int B) {
   planes(w.ff, M * f);
   // conv-phase scratch aliases the backward scratch (disjoint in time)
   const size_t mark = off;
-  planes(w.a1, Mt * kConv1K); planes(w.h1, Mt * d);
+  planes(w.a1, Mt * conv1_k(e->cfg.n_mels)); planes(w.h1, Mt * d);
   const size_t conv_end = off;
   off = mark;
   w.dx_a = (float*)take(M * d * 4); w.dx_b = (float*)take(M * d * 4); w.dln = (float*)take(M * d * 4);
@@ -319,9 +326,10 @@ int conv_stem(awt_encoder* e, const float* mel, int Bc, bf16_t* const a1[2], bf1
   const awt_encoder_cfg& c = e->cfg;
   const int S = c.n_ctx, T = 2 * S, d = c.d_model, terms = c.mfma_terms;
   const int M = Bc * S, Mt = Bc * T;
-  int rc = launch_im2col_conv1(e->ctx, mel, Bc, c.n_mels, T, kConv1K, a1[0], a1[1], s); if (rc) return rc;
+  const int k1 = conv1_k(c.n_mels);
+  int rc = launch_im2col_conv1(e->ctx, mel, Bc, c.n_mels, T, k1, a1[0], a1[1], s); if (rc) return rc;
   {
-    GemmSeg sg = seg_plain(a1[0], a1[1], kConv1K, e->conv1.w, 0, kConv1K, Mt);
+    GemmSeg sg = seg_plain(a1[0], a1[1], k1, e->conv1.w, 0, k1, Mt);
     GemmOut o{}; o.hi = h1[0]; o.lo = h1[1]; o.ldo = d; o.bias = e->conv1.bias; o.n_valid = d;
     rc = launch_gemm(e->ctx, Mt, d, &sg, 1, terms, EPI_BF16_GELU, o, s); if (rc) return rc;
   }
@@ -418,7 +426,7 @@ extern "C" int awt_encoder_create(awt_ctx* c, const awt_encoder_cfg* cfg, awt_en
   AWT_REQUIRE(!cfg->training || cfg->d_model <= 1024, AWT_ERR_INVALID, "encoder_create: training needs d_model <= 1024 (adapter-gradient reduction)");
   AWT_REQUIRE(cfg->n_heads > 0 && cfg->d_model == cfg->n_heads * 64, AWT_ERR_INVALID, "encoder_create: head_dim (d_model / n_heads) must be 64");
   AWT_REQUIRE(cfg->ffn_dim > 0 && cfg->ffn_dim % 128 == 0, AWT_ERR_INVALID, "encoder_create: ffn_dim must be a multiple of 128");
-  AWT_REQUIRE(cfg->n_mels > 0 && cfg->n_mels % 8 == 0 && 3 * cfg->n_mels <= kConv1K, AWT_ERR_INVALID, "encoder_create: n_mels must be a multiple of 8, <= 80");
+  AWT_REQUIRE(cfg->n_mels > 0 && cfg->n_mels % 8 == 0 && cfg->n_mels <= 128, AWT_ERR_INVALID, "encoder_create: n_mels must be a multiple of 8, <= 128");
   AWT_REQUIRE(cfg->n_layers > 0 && cfg->n_ctx > 0, AWT_ERR_INVALID, "encoder_create: n_layers and n_ctx must be positive");
   AWT_REQUIRE(cfg->mfma_terms == 1 || cfg->mfma_terms == 3, AWT_ERR_INVALID, "encoder_create: mfma_terms must be 1 or 3");
   AWT_REQUIRE(cfg->lora_rank >= 0 && cfg->lora_rank <= 32, AWT_ERR_INVALID, "encoder_create: lora_rank must be in 0..32");
@@ -429,7 +437,7 @@ extern "C" int awt_encoder_create(awt_ctx* c, const awt_encoder_cfg* cfg, awt_en
   e->ctx = c; e->cfg = *cfg; e->planes = cfg->mfma_terms == 3 ? 2 : 1;
   e->chunk = cfg->chunk_clips > 0 ? cfg->chunk_clips : 64;
   const int d = cfg->d_model, f = cfg->ffn_dim;
-  int rc = alloc_linear(e, &e->conv1, d, kConv1K);
+  int rc = alloc_linear(e, &e->conv1, d, conv1_k(cfg->n_mels));
   if (!rc) rc = alloc_linear(e, &e->conv2, d, 3 * d);
   if (!rc) rc = dev_alloc(e, (void**)&e->pos, (size_t)cfg->n_ctx * d * 4);
   if (!rc) rc = dev_alloc(e, (void**)&e->lnf_g, (size_t)d * 4);
@@ -581,7 +589,7 @@ extern "C" int awt_audio_encode(awt_encoder* e, const void* pcm, int pcm_is_i16,
                                 int max_valid, int B, float* features_out, float* hidden, void* workspace, size_t ws_bytes,
                                 void* stream) {
   AWT_REQUIRE(e && pcm && hidden && workspace && B > 0, AWT_ERR_INVALID, "audio_encode: bad argument");
-  AWT_REQUIRE(e->cfg.n_mels == 80, AWT_ERR_INVALID, "audio_encode: the Whisper front-end has 80 mel bins");
+  AWT_REQUIRE(e->cfg.n_mels == 80 || e->cfg.n_mels == 128, AWT_ERR_INVALID, "audio_encode: the Whisper front-end has 80 or 128 (large-v3) mel bins");
   int rc = require_weights(e); if (rc) return rc;
   AWT_REQUIRE(ws_bytes >= awt_audio_encode_workspace_bytes(e, B), AWT_ERR_WORKSPACE, "audio_encode: workspace too small");
   AWT_REQUIRE(((uintptr_t)workspace & 255) == 0, AWT_ERR_INVALID, "audio_encode: workspace must be 256-byte aligned");
@@ -591,13 +599,13 @@ extern "C" int awt_audio_encode(awt_encoder* e, const void* pcm, int pcm_is_i16,
   char* base = (char*)workspace;
   const size_t enc_bytes = carve(e, nullptr, chunk).bytes;
   float* mel_buf = (float*)(base + enc_bytes);
-  void* lm_ws = base + enc_bytes + align_up((size_t)chunk * 80 * T * 4);
+  void* lm_ws = base + enc_bytes + align_up((size_t)chunk * e->cfg.n_mels * T * 4);
   const size_t esz = pcm_is_i16 ? 2 : 4;
   for (int b0 = 0; b0 < B; b0 += chunk) {
     const int Bc = std::min(chunk, B - b0);
-    float* mel = features_out ? features_out + (size_t)b0 * 80 * T : mel_buf;
+    float* mel = features_out ? features_out + (size_t)b0 * e->cfg.n_mels * T : mel_buf;
     rc = logmel_whisper_impl(e->ctx, (const char*)pcm + (size_t)b0 * pcm_stride * esz, pcm_is_i16, pcm_stride,
-                             n_valid ? n_valid + b0 : nullptr, max_valid, Bc, T, mel, lm_ws, awt_logmel_workspace_bytes(Bc), s);
+                             n_valid ? n_valid + b0 : nullptr, max_valid, Bc, T, e->cfg.n_mels, mel, lm_ws, awt_logmel_workspace_bytes(Bc), s);
     if (rc) return rc;
     rc = forward_chunk(e, mel, Bc, hidden + (size_t)b0 * e->cfg.n_ctx * e->cfg.d_model, base, s);
     if (rc) return rc;

@@ -162,7 +162,7 @@ int launch_pack_weight(awt_ctx* c, const float* src, int N, int C, int taps, int
 int launch_im2col_conv1(awt_ctx* c, const float* mel, int B, int C, int T, int K_dst, bf16_t* hi, bf16_t* lo, hipStream_t s);
 
 int logmel_whisper_impl(awt_ctx* c, const void* pcm, int pcm_is_i16, int64_t pcm_stride, const int32_t* n_valid,
-                        int max_valid, int B, int n_frames_out, float* out, void* workspace, size_t ws_bytes, hipStream_t s);
+                        int max_valid, int B, int n_frames_out, int n_mels, float* out, void* workspace, size_t ws_bytes, hipStream_t s);
 int logmel_generic_impl(awt_ctx* c, const float* pcm, int64_t pcm_stride, int B, int n_samples, int sample_rate, int n_fft,
                         int hop, int n_mels, float f_min, float f_max, float log_eps, float* out, hipStream_t s);
 int prepare_waveform_impl(awt_ctx* c, const void* pcm, int pcm_is_i16, int channels, int64_t channel_stride, int64_t sample_stride,

@@ -333,13 +333,14 @@ int host_live_frames(int n_valid, int n_fft, int hop, int T_out) {
 size_t awt_logmel_workspace_bytes(int B) { return (((size_t)(B > 0 ? B : 1) * sizeof(unsigned)) + 255) & ~(size_t)255; }
 
 int logmel_whisper_impl(awt_ctx* c, const void* pcm, int pcm_is_i16, int64_t pcm_stride, const int32_t* n_valid,
-                        int max_valid, int B, int n_frames_out, float* out, void* workspace, size_t ws_bytes, hipStream_t s) {
+                        int max_valid, int B, int n_frames_out, int n_mels, float* out, void* workspace, size_t ws_bytes, hipStream_t s) {
   AWT_REQUIRE(c && pcm && out && workspace, AWT_ERR_INVALID, "logmel_whisper: null argument");
   AWT_REQUIRE(B > 0 && n_frames_out > 0 && n_frames_out % 4 == 0, AWT_ERR_INVALID, "logmel_whisper: B > 0 and n_frames_out % 4 == 0 required");
   AWT_REQUIRE(max_valid >= 0 && (pcm_stride >= max_valid || B == 1), AWT_ERR_INVALID, "logmel_whisper: pcm_stride < max_valid");
   AWT_REQUIRE(ws_bytes >= awt_logmel_workspace_bytes(B), AWT_ERR_WORKSPACE, "logmel_whisper: workspace too small");
   AWT_REQUIRE(((uintptr_t)out & 15) == 0, AWT_ERR_INVALID, "logmel_whisper: out must be 16-byte aligned");
-  const int n_fft = 400, hop = 160, n_mels = 80;
+  AWT_REQUIRE(n_mels == 80 || n_mels == 128, AWT_ERR_INVALID, "logmel_whisper: n_mels must be 80 (tiny .. large-v2) or 128 (large-v3)");
+  const int n_fft = 400, hop = 160;
   BasisTable bt; MelTable mt;
   int rc = get_basis(c, n_fft, s, &bt); if (rc) return rc;
   rc = get_mel(c, n_fft / 2 + 1, n_mels, 0.0, 8000.0, 16000, true, &mt); if (rc) return rc;

@@ -40,8 +40,9 @@ class BatchFeature(dict):
 
 
 def logmel_whisper_device(pcm: torch.Tensor, n_valid: Optional[torch.Tensor] = None, max_valid: Optional[int] = None,
-                          n_frames: int = 3000, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Device PCM [B, n] (int16 or float32, contiguous rows) -> device float32 [B, 80, n_frames].  No host round trip."""
+                          n_frames: int = 3000, out: Optional[torch.Tensor] = None, n_mels: int = 80) -> torch.Tensor:
+    """Device PCM [B, n] (int16 or float32, contiguous rows) -> device float32 [B, n_mels, n_frames] (n_mels 80, or 128
+    for large-v3).  No host round trip."""
     if pcm.dim() != 2 or pcm.dtype not in (torch.int16, torch.float32):
         raise ValueError("pcm must be a [B, n] int16 or float32 device tensor")
     B, n = pcm.shape
@@ -54,13 +55,13 @@ def logmel_whisper_device(pcm: torch.Tensor, n_valid: Optional[torch.Tensor] = N
         if n_valid.numel() != B:
             raise ValueError("n_valid must have one entry per clip")
     if out is None:
-        out = torch.empty((B, 80, n_frames), dtype=torch.float32, device=pcm.device)
+        out = torch.empty((B, n_mels, n_frames), dtype=torch.float32, device=pcm.device)
     L = _lib.lib()
     ws = _lib.workspace(L.awt_logmel_workspace_bytes(B), pcm.device)
     with torch.cuda.device(pcm.device):
-        _lib.check(L.awt_logmel_whisper(_lib.ctx(pcm.device), _lib.ptr(pcm), int(pcm.dtype == torch.int16), pcm.stride(0),
-                                        _lib.ptr(n_valid), int(max_valid), B, n_frames, _lib.ptr(out), _lib.ptr(ws), ws.numel(),
-                                        _lib.stream_handle()))
+        _lib.check(L.awt_logmel_whisper_mels(_lib.ctx(pcm.device), _lib.ptr(pcm), int(pcm.dtype == torch.int16), pcm.stride(0),
+                                             _lib.ptr(n_valid), int(max_valid), B, n_frames, int(n_mels), _lib.ptr(out), _lib.ptr(ws),
+                                             ws.numel(), _lib.stream_handle()))
     return out
 
 
@@ -71,8 +72,8 @@ class WhisperFeatureExtractor:
 
     def __init__(self, feature_size: int = 80, sampling_rate: int = 16000, hop_length: int = 160, chunk_length: int = 30,
                  n_fft: int = 400, padding_value: float = 0.0, return_attention_mask: bool = False, device: str = "cuda"):
-        if (feature_size, sampling_rate, hop_length, n_fft) != (80, 16000, 160, 400):
-            raise ValueError("the native extractor implements Whisper's front-end: 80 mels, 16 kHz, hop 160, n_fft 400")
+        if feature_size not in (80, 128) or (sampling_rate, hop_length, n_fft) != (16000, 160, 400):
+            raise ValueError("the native extractor implements Whisper's front-end: 80 or 128 mels, 16 kHz, hop 160, n_fft 400")
         self.feature_size, self.sampling_rate, self.hop_length, self.n_fft = feature_size, sampling_rate, hop_length, n_fft
         self.chunk_length = chunk_length
         self.n_samples = chunk_length * sampling_rate
@@ -109,7 +110,7 @@ class WhisperFeatureExtractor:
             host[i, : lens[i]] = torch.from_numpy(c[: lens[i]])
         dev = torch.device(device or self.device)
         pcm = host.to(dev, non_blocking=True)
-        feats = logmel_whisper_device(pcm, torch.from_numpy(lens), int(lens.max()), n_frames)
+        feats = logmel_whisper_device(pcm, torch.from_numpy(lens), int(lens.max()), n_frames, n_mels=self.feature_size)
         out = BatchFeature()
         feats_cpu = feats.cpu()  # the reference's extractor returns host arrays
         want_mask = self.return_attention_mask if return_attention_mask is None else return_attention_mask

@@ -125,7 +125,8 @@ CONFIGS: Dict[str, EncoderConfig] = {
     "base": EncoderConfig(512, 6, 8, 2048, 80, 1500, "base"),
     "small": EncoderConfig(768, 12, 12, 3072, 80, 1500, "small"),
     "medium": EncoderConfig(1024, 24, 16, 4096, 80, 1500, "medium"),
-    "large": EncoderConfig(1280, 32, 20, 5120, 80, 1500, "large"),   # large / large-v2 (80 mel bins; v3's 128 is not supported)
+    "large": EncoderConfig(1280, 32, 20, 5120, 80, 1500, "large"),   # large / large-v2 (80 mel bins)
+    "large-v3": EncoderConfig(1280, 32, 20, 5120, 128, 1500, "large-v3"),   # 128 mel bins (also the turbo checkpoints' encoder)
 }
 
 

@@ -83,9 +83,9 @@ def mel_filter_bank(num_frequency_bins: int, num_mel_filters: int, min_frequency
     return fb
 
 
-def whisper_mel_filters() -> np.ndarray:
-    """HF:feature_extraction_whisper.py:95-103."""
-    return mel_filter_bank(1 + WHISPER_N_FFT // 2, WHISPER_N_MELS, 0.0, 8000.0, WHISPER_SR, "slaney", "slaney")
+def whisper_mel_filters(n_mels: int = WHISPER_N_MELS) -> np.ndarray:
+    """HF:feature_extraction_whisper.py:95-103 (`feature_size` = 80, or 128 for large-v3)."""
+    return mel_filter_bank(1 + WHISPER_N_FFT // 2, n_mels, 0.0, 8000.0, WHISPER_SR, "slaney", "slaney")
 
 
 def hann_periodic(n: int) -> np.ndarray:
@@ -120,8 +120,8 @@ def pad_or_trim(waveform: np.ndarray, n_samples: int) -> np.ndarray:
     return np.concatenate([w, np.zeros(n_samples - w.size, dtype=np.float32)])
 
 
-def whisper_logmel(clips, n_samples: int = WHISPER_N_SAMPLES) -> np.ndarray:
-    """[B, 80, n_samples // 160] fp32 Whisper input features for a list of mono fp32 clips.
+def whisper_logmel(clips, n_samples: int = WHISPER_N_SAMPLES, n_mels: int = WHISPER_N_MELS) -> np.ndarray:
+    """[B, n_mels, n_samples // 160] fp32 Whisper input features for a list of mono fp32 clips.
 
     n_samples = 480000 is the reference's behaviour (parity mode, T = 3000);
     n_samples = 64000 is the trimmed mode (T = 400) which the reference never computes.
@@ -129,7 +129,7 @@ def whisper_logmel(clips, n_samples: int = WHISPER_N_SAMPLES) -> np.ndarray:
     """
     if isinstance(clips, np.ndarray) and clips.ndim == 1:
         clips = [clips]
-    filters = whisper_mel_filters()
+    filters = whisper_mel_filters(n_mels)
     out = []
     for clip in clips:
         w = pad_or_trim(clip, n_samples)

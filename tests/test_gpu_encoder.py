@@ -18,7 +18,7 @@ FAST_TOL = {"max_abs": 8e-2, "rel_l2": 1.2e-2}
 
 
 def _mel(cfg, batch, first=0):
-    return oracle_mel.whisper_logmel(piano_clips_f32(batch, first), n_samples=2 * cfg.max_source_positions * 160)
+    return oracle_mel.whisper_logmel(piano_clips_f32(batch, first), n_samples=2 * cfg.max_source_positions * 160, n_mels=cfg.n_mels)
 
 
 def _native(cfg, precision, profile="test", lora=None, chunk=0):
@@ -28,7 +28,7 @@ def _native(cfg, precision, profile="test", lora=None, chunk=0):
 
 @pytest.mark.parametrize("name,trimmed,batch", [("mini", True, 2), ("mini", False, 1), ("tiny", True, 2), ("tiny", False, 2),
                                                 ("small", True, 2), ("small", False, 2), ("base", True, 2), ("base", False, 1),
-                                                ("medium", True, 1), ("medium", False, 1), ("large", True, 1)])
+                                                ("medium", True, 1), ("medium", False, 1), ("large", True, 1), ("large-v3", True, 1)])
 def test_encoder_parity_mode_vs_oracle_and_golden(name, trimmed, batch):
     cfg = wts.config(name, trimmed)
     W = wts.init_encoder_weights(cfg, 0, "test")
@@ -38,7 +38,7 @@ def test_encoder_parity_mode_vs_oracle_and_golden(name, trimmed, batch):
     ref = oracle_enc.encoder_forward(W, mel, cfg.heads).numpy()
     e = oracle_enc.error_norms(out, ref)
     assert e["max_abs"] < PARITY_TOL, e
-    G = golden("encoder.npz" if name in ("mini", "tiny", "small") else "encoder_large.npz")
+    G = golden("encoder.npz" if name in ("mini", "tiny", "small") else ("encoder_v3.npz" if name == "large-v3" else "encoder_large.npz"))
     key = cfg.name
     np.testing.assert_allclose(out[:, :4], G[f"{key}/last_head"], rtol=0, atol=PARITY_TOL)
     np.testing.assert_allclose(out[:, -4:], G[f"{key}/last_tail"], rtol=0, atol=PARITY_TOL)
@@ -131,3 +131,26 @@ def test_whisper_audio_encoder_matches_per_sample_reference_semantics():
     assert out.shape == (2, 1500, 128) and np.abs(out - ref).max() < PARITY_TOL
     with pytest.raises(ValueError, match="16000"):
         tower(ragged, 8000)
+
+
+def test_large_v3_front_end_and_pcm_path():
+    """128 mel bins (large-v3): the device extractor against transformers' own feature_size=128 output, and PCM -> hidden
+    states in one call against mel -> hidden states."""
+    from mlx8_ws_audio_transformer_amd import synth
+    from mlx8_ws_audio_transformer_amd.feature_extraction import WhisperFeatureExtractor, logmel_whisper_device
+    cfg = wts.config("large-v3", True)
+    G = golden("encoder_v3.npz")
+    pcm_f32 = piano_clips_f32(1)
+    fe = WhisperFeatureExtractor(feature_size=128)
+    feats = fe(pcm_f32, sampling_rate=16000, return_tensors="np", max_length=64000)["input_features"]
+    assert feats.shape == (1, 128, 400)
+    ref = G["large-v3-trimmed/mel_probe"][:, :, :400]          # transformers' fp32 torch.stft path: see tests/test_oracle_encoder.py
+    np.testing.assert_allclose(feats, ref, rtol=0, atol=1e-4)
+    assert np.mean(np.abs(feats - ref) > 2e-6) < 0.02
+    np.testing.assert_allclose(feats, oracle_mel.whisper_logmel(pcm_f32, n_samples=64000, n_mels=128), rtol=0, atol=1e-5)
+    enc = _native(cfg, "bf16x3")
+    pcm = torch.from_numpy(synth.synth_clips_i16(1, seed=1234)).cuda()
+    mel = logmel_whisper_device(pcm, n_frames=400, n_mels=128)
+    a = enc.encode_pcm(pcm)
+    b = enc(mel).last_hidden_state
+    assert torch.equal(a, b)

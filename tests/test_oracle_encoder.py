@@ -8,16 +8,16 @@ from mlx8_ws_audio_transformer_amd import weights as wts
 from oracle import encoder, logmel
 from tests.util import golden, piano_clips_f32
 
-G = {**golden("encoder.npz"), **golden("encoder_large.npz")}   # second file: base / medium / large (tools/make_golden.py encoder_large)
+G = {**golden("encoder.npz"), **golden("encoder_large.npz"), **golden("encoder_v3.npz")}   # second file: base / medium / large (tools/make_golden.py encoder_large)
 
 
 def _mel(cfg, batch):
-    return logmel.whisper_logmel(piano_clips_f32(batch), n_samples=2 * cfg.max_source_positions * 160)
+    return logmel.whisper_logmel(piano_clips_f32(batch), n_samples=2 * cfg.max_source_positions * 160, n_mels=cfg.n_mels)
 
 
 @pytest.mark.parametrize("name,trimmed,batch", [("mini", False, 1), ("mini", True, 2), ("tiny", True, 2),
                                                 ("tiny", False, 2), ("small", True, 2), ("base", True, 2),
-                                                ("medium", True, 1), ("large", True, 1)])
+                                                ("medium", True, 1), ("large-v3", True, 1)])   # large (80 mels, d 1280) is covered on the GPU side only: host weight init is slow
 def test_encoder_matches_reference(name, trimmed, batch):
     cfg = wts.config(name, trimmed)
     W = wts.init_encoder_weights(cfg, seed=0, profile="test")
@@ -25,6 +25,11 @@ def test_encoder_matches_reference(name, trimmed, batch):
     assert bytes.fromhex(wts.weights_digest(W)) == G[f"{key}/weights_sha256"].tobytes()
     mel = _mel(cfg, batch)
     assert abs(mel.astype(np.float64).sum() - float(G[f"{key}/mel_sum"])) < 0.5  # inputs agree (<=1e-5 per bin)
+    if f"{key}/mel_probe" in G:                                                   # 128-bin extractor (large-v3) against HF's own output
+        # transformers took its fp32 torch.stft path for this fixture; on the digitally silent gaps of the piano clips that path
+        # deviates from its own float64 NumPy path (which the oracle follows) by up to 3.9e-5 in ~1 % of the bins
+        np.testing.assert_allclose(mel[:, :, :420], G[f"{key}/mel_probe"], rtol=0, atol=1e-4)
+        assert np.mean(np.abs(mel[:, :, :420] - G[f"{key}/mel_probe"]) > 2e-6) < 0.02
     out, bounds = encoder.encoder_forward(W, mel, cfg.heads, return_boundaries=True)
     out = out.numpy()
     tol = 2e-4  # fp32 op-order noise amplified by the mel input difference (<= 1e-5 per bin)

@@ -100,7 +100,7 @@ def encoder_mel(cfg: wts.EncoderConfig, batch: int):
     """Input features for the encoder fixtures: HF extractor on seeded piano clips."""
     from transformers import WhisperFeatureExtractor
 
-    fe = WhisperFeatureExtractor()
+    fe = WhisperFeatureExtractor(feature_size=cfg.n_mels)
     clips = [synth.pcm_i16_to_f32(c) for c in synth.synth_clips_i16(batch, seed=1234, first=0)]
     n = 2 * cfg.max_source_positions * 160
     return fe(clips, sampling_rate=16000, return_tensors="np", max_length=n)["input_features"].astype(np.float32)
@@ -111,6 +111,7 @@ ENCODER_CASES = [("mini", False, 1, True), ("mini", True, 2, True), ("tiny", Fal
 # the other Whisper sizes (own file, so the round-1 fixtures above stay byte-identical)
 ENCODER_CASES_LARGE = [("base", True, 2, False), ("base", False, 1, False), ("medium", True, 1, False), ("medium", False, 1, False),
                        ("large", True, 1, False)]
+ENCODER_CASES_V3 = [("large-v3", True, 1, False)]      # 128 mel bins: extractor with feature_size=128
 
 
 def gen_encoder(cases=ENCODER_CASES, fname="encoder.npz"):
@@ -135,6 +136,8 @@ def gen_encoder(cases=ENCODER_CASES, fname="encoder.npz"):
         if full:
             out[f"{key}/last_full"] = last
         print(key, "encoder fixture done", last.shape)
+        if cfg.n_mels != 80:
+            out[f"{key}/mel_probe"] = mel[:, :, :420]      # the 128-bin extractor's own output (live frames + first padding frames)
     # sinusoid rows (fixture F5) from the HF module itself
     from transformers.models.whisper.modeling_whisper import sinusoids
     tab = sinusoids(1500, 768).numpy()
@@ -237,6 +240,8 @@ if __name__ == "__main__":
         gen_encoder()
     if "decoder" in what:
         gen_decoder()
+    if "encoder_v3" in what:
+        gen_encoder(ENCODER_CASES_V3, "encoder_v3.npz")
     if "encoder_large" in what:
         gen_encoder(ENCODER_CASES_LARGE, "encoder_large.npz")
     if "collator" in what:
