@@ -154,3 +154,26 @@ def test_large_v3_front_end_and_pcm_path():
     a = enc.encode_pcm(pcm)
     b = enc(mel).last_hidden_state
     assert torch.equal(a, b)
+
+
+def test_forward_is_hip_graph_capturable():
+    """PCM -> hidden states records into a HIP graph (torch.cuda.CUDAGraph on the caller's stream: no allocation, copy or
+    synchronisation inside the library once tables and weights are resident) and replays bit-identically."""
+    from mlx8_ws_audio_transformer_amd import synth
+    cfg = wts.config("tiny", True)
+    enc = _native(cfg, "bf16x3")
+    pcm = torch.from_numpy(synth.synth_clips_i16(2, seed=1234)).cuda()
+    ref = enc.encode_pcm(pcm).clone()
+    static_pcm = torch.zeros_like(pcm)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        enc.encode_pcm(static_pcm)                       # warm-up on the capture stream
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = enc.encode_pcm(static_pcm)
+    static_pcm.copy_(pcm)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
