@@ -399,7 +399,9 @@ int launch_epi(GemmArgs a, int terms, hipStream_t s) {
   if (tile == 256 && a.N % 256 != 0) tile = 128;
   if (tile == 256) return terms == 3 ? launch_one<3, 32, EPI, CfgW4>(a, s) : launch_one<1, 64, EPI, CfgW4>(a, s);
   if (tile == 128) return terms == 3 ? launch_one<3, 32, EPI, Cfg128>(a, s) : launch_one<1, 64, EPI, Cfg128>(a, s);
-  return terms == 3 ? launch_one<3, 32, EPI, Cfg64>(a, s) : launch_one<1, 64, EPI, Cfg64>(a, s);
+  // few tiles per CU: the K loop is latency-bound (one barrier + one global round trip per K-tile), so the deeper 64-wide
+  // K-tile is used for the split product as well (its 64 + 64 weight-fragment registers fit next to 32 accumulators)
+  return terms == 3 ? launch_one<3, 64, EPI, Cfg64>(a, s) : launch_one<1, 64, EPI, Cfg64>(a, s);
 }
 
 
