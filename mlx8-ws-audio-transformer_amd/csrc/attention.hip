@@ -13,7 +13,7 @@
 //    address; K fragments are ds_read_b128 rows, V^T fragments come from the hardware transpose read
 //    ds_read_b64_tr_b16 in the permuted key order the P operand has.
 //  * TERMS = 3 runs both products in split-bf16 (q, k, v and P as hi + lo planes, three MFMAs per fragment pair).
-//  * each wave owns QT = 2 query tiles (64 queries): K / V fragments, the LDS tile, its DMA and the barrier are amortised
+//  * each wave owns QT = 2 query tiles (64 queries; QT = 1 for small grids): K / V fragments, the LDS tile, its DMA and the barrier are amortised
 //    over 96 MFMAs instead of 48;
 //  * fp32 running max / sum / output accumulators; S = 1500 is not a multiple of 64: tail keys are masked,
 //    tail rows clamped on load and skipped on store.
@@ -23,12 +23,9 @@
 namespace {
 
 constexpr int kThreads = 256;
-#ifndef AWT_ATTN_QT
-#define AWT_ATTN_QT 2
-#endif
-constexpr int QT = AWT_ATTN_QT;   // 32-query tiles per wave (K / V fragments, LDS tiles and the barrier are amortised over QT x 48 MFMAs)
-constexpr int QW = 32 * QT;       // queries per wave
-constexpr int QB = 4 * QW;        // queries per workgroup
+// QT (template parameter) = 32-query tiles per wave: K / V fragments, LDS tiles and the barrier are amortised over QT x 48
+// MFMAs.  QT = 2 for full launches; QT = 1 (twice the workgroups, half the time per K/V tile) when the grid would not
+// fill the chip's 512 workgroup slots (one or two clips).
 #ifndef AWT_ATTN_KB
 #define AWT_ATTN_KB 64
 #endif
@@ -76,8 +73,10 @@ __device__ __forceinline__ bf16x4 tr_read(const char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)p);
 }
 
-template <int TERMS>
+template <int TERMS, int QT>
 __global__ __launch_bounds__(kThreads, 2) void attention_kernel(AttnArgs a) {
+  constexpr int QW = 32 * QT;       // queries per wave
+  constexpr int QB = 4 * QW;        // queries per workgroup
   constexpr int NPL = TERMS == 3 ? 4 : 2;
   constexpr int STAGE = NPL * PLANE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -300,12 +299,13 @@ __global__ __launch_bounds__(kThreads, 2) void attention_kernel(AttnArgs a) {
   }
 }
 
-template <int TERMS>
+template <int TERMS, int QT>
 int launch_t(const AttnArgs& a, hipStream_t s) {
   constexpr int lds = 2 * (TERMS == 3 ? 4 : 2) * PLANE;
-  AWT_ONCE_PER_DEVICE(AWT_HIP_CHECK(hipFuncSetAttribute((const void*)attention_kernel<TERMS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)));
+  constexpr int QB = 4 * 32 * QT;
+  AWT_ONCE_PER_DEVICE(AWT_HIP_CHECK(hipFuncSetAttribute((const void*)attention_kernel<TERMS, QT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)));
   dim3 grid(((a.S + QB - 1) / QB) * a.B * a.H);
-  hipLaunchKernelGGL(attention_kernel<TERMS>, grid, dim3(kThreads), lds, s, a);
+  hipLaunchKernelGGL((attention_kernel<TERMS, QT>), grid, dim3(kThreads), lds, s, a);
   AWT_HIP_CHECK(hipGetLastError());
   return AWT_OK;
 }
@@ -321,5 +321,7 @@ int launch_attention(awt_ctx* c, const bf16_t* q_hi, const bf16_t* q_lo, const b
   AWT_REQUIRE(terms == 1 || (q_lo && k_lo && v_lo), AWT_ERR_INVALID, "attention: lo planes required for terms == 3");
   AttnArgs a{q_hi, q_lo, k_hi, k_lo, v_hi, v_lo, o_hi, o_lo, o_f32, lse, B, H, S};
   ProfScope prof(c, AWT_PROF_ATTENTION, s, 4.0 * (double)B * H * (double)S * S * 64);
-  return terms == 3 ? launch_t<3>(a, s) : launch_t<1>(a, s);
+  const bool small_grid = (int64_t)((S + 255) / 256) * B * H < 512;   // fewer 256-query workgroups than slots: halve them
+  if (small_grid) return terms == 3 ? launch_t<3, 1>(a, s) : launch_t<1, 1>(a, s);
+  return terms == 3 ? launch_t<3, 2>(a, s) : launch_t<1, 2>(a, s);
 }
