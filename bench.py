@@ -188,7 +188,7 @@ def main():
     terms = 3 if a.precision == "bf16x3" else 1
     props = torch.cuda.get_device_properties(dev)
     device_info = {"name": props.name, "arch": getattr(props, "gcnArchName", ""), "compute_units": props.multi_processor_count,
-                   "hbm_gib": round(props.total_memory / 2 ** 30, 1), "max_sclk_mhz": round(getattr(props, "clock_rate", 0) / 1e3),
+                   "hbm_gib": round(props.total_memory / 2 ** 30, 1),
                    "note": "peaks used: 2.5 PFLOP/s dense bf16 MFMA, 8 TB/s HBM3E (MI355X_MICROARCH.md); the encoder runs at the "
                            "1400 W package limit with sclk 1.9-2.1 GHz (DESIGN.md 4.2)"}
     result = {
