@@ -109,6 +109,26 @@ def finetune_main(a, rank, local_rank, world, dev):
         dist.destroy_process_group()
 
 
+def sample_power(step, dev, steps=40):
+    """Queues `steps` more (untimed) steps and reads rocm-smi while the GPU works through them.  None if rocm-smi is missing."""
+    import re
+    import subprocess
+    try:
+        for _ in range(steps):
+            step()
+        time.sleep(0.3)
+        txt = subprocess.run(["rocm-smi", "--showpower", "--showclocks"], capture_output=True, text=True, timeout=20).stdout
+        torch.cuda.synchronize(dev)
+        watts = [float(x) for x in re.findall(r"Power \(W\):\s*([0-9.]+)", txt)]
+        sclk = [int(x) for x in re.findall(r"sclk clock level:\s*\d+:\s*\((\d+)Mhz\)", txt)]
+        if not watts or not sclk:
+            return None
+        return {"package_w": max(watts), "sclk_mhz": min(sclk), "note": "rocm-smi sampled once while the headline workload was running (untimed)"}
+    except Exception:
+        torch.cuda.synchronize(dev)
+        return None
+
+
 def timed_steps(enc, pcm, steps, world, dev):
     """barrier + synchronize on both sides, returns max-over-ranks seconds for exactly `steps` steps."""
     import torch.distributed as dist
@@ -226,6 +246,9 @@ def main():
         result["end_to_end_frac_of_mfma_peak"] = round(value * gf / 1e3 / PEAK_BF16_DENSE_TFLOPS / world, 4)
 
     if rank == 0 and world == 1:
+        # ---- package power and shader clock while the headline workload runs (rocm-smi in a child process, outside the timed
+        #      region): the encoder sits at the package power limit, which is what caps roofline.frac
+        result["power"] = sample_power(lambda: enc.encode_pcm(pcm), dev)
         # ---- single-pass bf16 mode, reported beside the headline (it does not meet the 1e-3 bound)
         if not a.no_fast_mode and a.precision == "bf16x3":
             fast = NativeWhisperEncoder(cfg, precision="bf16", device=str(dev), chunk_clips=a.chunk, seed=0, init_profile="hf").eval()
