@@ -177,3 +177,38 @@ def test_forward_is_hip_graph_capturable():
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+def test_every_gemm_tiling_gives_the_same_bits(precision):
+    """The three block tilings (64 x 128, 128 x 128, 128 x 256) accumulate every output element over k in the same order,
+    so the whole encoder -- conv-stem segments with row maps, LoRA segments, every fused epilogue -- must agree bit for
+    bit whichever tiling is forced."""
+    from mlx8_ws_audio_transformer_amd import _lib
+    cfg = wts.config("tiny", True)          # d = 384: qkv N = 1152 and out / fc2 N = 384 fall back from 256 to 128 on their own
+    lora = wts.LoraSpec(r=8, alpha=16.0, targets=("q_proj", "v_proj"))
+    enc = _native(cfg, precision, lora=lora)
+    for name, p in enc.named_parameters():
+        if name.endswith("lora_B"):
+            with torch.no_grad():
+                p.copy_(torch.from_numpy(0.05 * wts.unit_variates(name, p.numel(), 2).reshape(p.shape).astype(np.float32)))
+    mel = torch.from_numpy(_mel(cfg, 3)).cuda()
+    outs = []
+    for tile in (0, 64, 128, 256):
+        _lib.tuning_set("gemm_tile", tile)
+        try:
+            outs.append(enc(mel).last_hidden_state.clone())
+        finally:
+            _lib.tuning_set("gemm_tile", 0)
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    cfg2 = wts.config("mini", False)        # d = 128, S = 1500
+    enc2 = _native(cfg2, precision)
+    mel2 = torch.from_numpy(_mel(cfg2, 1)).cuda()
+    ref = enc2(mel2).last_hidden_state.clone()
+    for tile in (64, 128):
+        _lib.tuning_set("gemm_tile", tile)
+        try:
+            assert torch.equal(enc2(mel2).last_hidden_state, ref)
+        finally:
+            _lib.tuning_set("gemm_tile", 0)
