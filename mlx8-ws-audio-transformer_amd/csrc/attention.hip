@@ -321,7 +321,11 @@ int launch_attention(awt_ctx* c, const bf16_t* q_hi, const bf16_t* q_lo, const b
   AWT_REQUIRE(terms == 1 || (q_lo && k_lo && v_lo), AWT_ERR_INVALID, "attention: lo planes required for terms == 3");
   AttnArgs a{q_hi, q_lo, k_hi, k_lo, v_hi, v_lo, o_hi, o_lo, o_f32, lse, B, H, S};
   ProfScope prof(c, AWT_PROF_ATTENTION, s, 4.0 * (double)B * H * (double)S * S * 64);
-  const bool small_grid = (int64_t)((S + 255) / 256) * B * H < 512;   // fewer 256-query workgroups than slots: halve them
-  if (small_grid) return terms == 3 ? launch_t<3, 1>(a, s) : launch_t<1, 1>(a, s);
+  // 512 workgroup slots (256 CUs x 2): a launch lasts ceil(workgroups / 512) rounds.  One query tile per wave doubles the
+  // workgroups at ~0.55 of the duration each (less K / V amortisation); take it when that is fewer round-equivalents --
+  // grids under one round, and grids whose last round would be mostly empty (Whisper-tiny at B = 32: 3 rounds vs 2.75).
+  const int64_t wg2 = (int64_t)((S + 255) / 256) * B * H, wg1 = (int64_t)((S + 127) / 128) * B * H;
+  const double cost2 = (double)((wg2 + 511) / 512), cost1 = 0.55 * (double)((wg1 + 511) / 512);
+  if (cost1 < cost2) return terms == 3 ? launch_t<3, 1>(a, s) : launch_t<1, 1>(a, s);
   return terms == 3 ? launch_t<3, 2>(a, s) : launch_t<1, 2>(a, s);
 }
