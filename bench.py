@@ -56,6 +56,8 @@ def parse():
                     help="encode (default, the headline metric) or finetune: one LoRA step = fwd + bwd + all-reduce + AdamW")
     ap.add_argument("--lora-r", type=int, default=8)
     ap.add_argument("--decoder-dtype", default="fp32", choices=["fp32", "bf16"], help="finetune workload: dtype of the stock-PyTorch decoder")
+    ap.add_argument("--backward-precision", default=None, choices=["bf16"],
+                    help="finetune workload: gradient contractions in single bf16 products (opt-in; default = the forward's precision)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL, the real multi-GPU path) or gloo (rehearsal of the N > 1 code path on one GPU: every rank on cuda:0)")
     return ap.parse_args()
@@ -72,7 +74,8 @@ def finetune_main(a, rank, local_rank, world, dev):
     B = a.batch
     pcm = torch.from_numpy(synth.synth_clips_i16(B, seed=1234, first=rank * B)).to(dev)
     model = WhisperLoRAModel(cfg, wts.LoraSpec(r=a.lora_r, alpha=16.0), precision=a.precision, device=str(dev),
-                             decoder_autocast=torch.bfloat16 if a.decoder_dtype == "bf16" else None)
+                             decoder_autocast=torch.bfloat16 if a.decoder_dtype == "bf16" else None,
+                             backward_precision=a.backward_precision)
     g = torch.Generator().manual_seed(rank)
     labels = torch.randint(0, 51864, (B, 12), generator=g); labels[:, 0] = 50258
     args = Seq2SeqTrainingArguments(per_device_train_batch_size=B, learning_rate=1e-5, max_steps=10 ** 6, predict_with_generate=False)
@@ -103,6 +106,7 @@ def finetune_main(a, rank, local_rank, world, dev):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "LoRA r=%d (q_proj, v_proj) fine-tune step: log-mel + encoder fwd/bwd (HIP) + decoder/CE (torch) + all-reduce + AdamW" % a.lora_r,
                        "clips_per_gpu_per_step": B, "global_batch": B * world, "precision": a.precision, "label_tokens": 12, "decoder_dtype": a.decoder_dtype,
+                       "backward_precision": a.backward_precision or a.precision,
                        "adapter_grad_elems": tr.bucket.numel, "parallelism": "dp%d, one RCCL all-reduce of %.2f MB per step" % (world, tr.bucket.numel * 4 / 1e6)},
             "last_loss": loss}))
     if world > 1:

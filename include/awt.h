@@ -109,6 +109,10 @@ typedef struct awt_encoder_cfg {
   int32_t chunk_clips;      /* clips processed per kernel wave (0 = library default)                       */
   int32_t training;         /* != 0: keep transposed copies of the frozen weights so awt_encoder_backward can run
                                (adapters on q/k/v only in this mode)                                        */
+  int32_t backward_terms;   /* products of the backward pass' gradient contractions: 0 = mfma_terms (default: gradients
+                               to 3e-5 of fp32 autograd), 1 with mfma_terms = 3 = one bf16 product (the usual
+                               mixed-precision trade: ~0.5 % gradient error, 1.4x faster step); the attention scores are
+                               recomputed in split-bf16 either way                                            */
 } awt_encoder_cfg;
 
 enum { AWT_LORA_Q = 1, AWT_LORA_K = 2, AWT_LORA_V = 4, AWT_LORA_OUT = 8, AWT_LORA_FC1 = 16, AWT_LORA_FC2 = 32 };

@@ -28,7 +28,7 @@ class AwtError(RuntimeError):
 class EncoderCfg(C.Structure):
     _fields_ = [("d_model", C.c_int32), ("n_layers", C.c_int32), ("n_heads", C.c_int32), ("ffn_dim", C.c_int32),
                 ("n_mels", C.c_int32), ("n_ctx", C.c_int32), ("mfma_terms", C.c_int32), ("lora_rank", C.c_int32),
-                ("lora_alpha", C.c_float), ("lora_targets", C.c_uint32), ("chunk_clips", C.c_int32), ("training", C.c_int32)]
+                ("lora_alpha", C.c_float), ("lora_targets", C.c_uint32), ("chunk_clips", C.c_int32), ("training", C.c_int32), ("backward_terms", C.c_int32)]
 
 
 LORA_BITS = {"q_proj": 1, "k_proj": 2, "v_proj": 4, "out_proj": 8, "fc1": 16, "fc2": 32}

@@ -138,7 +138,7 @@ __device__ __forceinline__ void store_grad(const BwdArgs& a, const f32x16 (&acc)
     }
 }
 
-template <int TERMS, int MODE>
+template <int TERMS, int MODE, int GT>
 __global__ __launch_bounds__(kThreads, 2) void attention_bwd_kernel(BwdArgs a) {
   constexpr int NPL = TERMS == 3 ? 4 : 2;
   constexpr int STAGE = NPL * PLANE + 512;        // + [64] lse2 and [64] delta of the streamed rows (MODE_DKV)
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(kThreads, 2) void attention_bwd_kernel(BwdArgs a) {
       // s (scores) and dp for this 32-row sub-tile: rows = streamed rows (registers), cols = lanes
       f32x16 sacc = (f32x16){}, dpacc = (f32x16){};
       rows_times_lane<TERMS>(sacc, t1_hi, t1_lo, roff, sub, l1h, l1l);
-      rows_times_lane<TERMS>(dpacc, t2_hi, t2_lo, roff, sub, l2h, l2l);
+      rows_times_lane<GT>(dpacc, t2_hi, t2_lo, roff, sub, l2h, l2l);
       // MODE_DQ: s^T = K q^T (rows keys), dp^T = V dO^T.   MODE_DKV: s = Q k^T (rows queries), dp = dO v^T.
       f32x16 pacc, dsacc;
 #pragma unroll
@@ -229,8 +229,8 @@ __global__ __launch_bounds__(kThreads, 2) void attention_bwd_kernel(BwdArgs a) {
         pacc[r] = pv;
         dsacc[r] = pv * (dpacc[r] - dl);
       }
-      trT_times_acc<TERMS>(g1, t1_hi, t1_lo, sub, dsacc, toff, toffx);             // dQ^T += K^T dS^T   |  dK^T += Q^T dS
-      if (MODE == MODE_DKV) trT_times_acc<TERMS>(g2, t2_hi, t2_lo, sub, pacc, toff, toffx);   // dV^T += dO^T P
+      trT_times_acc<GT>(g1, t1_hi, t1_lo, sub, dsacc, toff, toffx);             // dQ^T += K^T dS^T   |  dK^T += Q^T dS
+      if (MODE == MODE_DKV) trT_times_acc<GT>(g2, t2_hi, t2_lo, sub, pacc, toff, toffx);   // dV^T += dO^T P
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -278,12 +278,14 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* do_hi, co
   }
 }
 
-template <int TERMS, int MODE>
+// GT = products of the GRADIENT contractions (dp, dq, dk, dv): TERMS, or 1 with TERMS = 3 (the opt-in bf16 backward: the
+// scores are still recomputed in split-bf16, because p = exp2(s - lse) has to reproduce the forward's probabilities)
+template <int TERMS, int MODE, int GT>
 int launch_mode(const BwdArgs& a, hipStream_t s) {
   constexpr int lds = 2 * ((TERMS == 3 ? 4 : 2) * PLANE + 512);
-  AWT_ONCE_PER_DEVICE(AWT_HIP_CHECK(hipFuncSetAttribute((const void*)attention_bwd_kernel<TERMS, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)));
+  AWT_ONCE_PER_DEVICE(AWT_HIP_CHECK(hipFuncSetAttribute((const void*)attention_bwd_kernel<TERMS, MODE, GT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)));
   dim3 grid(((a.S + LB - 1) / LB) * a.B * a.H);
-  hipLaunchKernelGGL((attention_bwd_kernel<TERMS, MODE>), grid, dim3(kThreads), lds, s, a);
+  hipLaunchKernelGGL((attention_bwd_kernel<TERMS, MODE, GT>), grid, dim3(kThreads), lds, s, a);
   AWT_HIP_CHECK(hipGetLastError());
   return AWT_OK;
 }
@@ -293,8 +295,9 @@ int launch_mode(const BwdArgs& a, hipStream_t s) {
 int launch_attention_bwd(awt_ctx* c, const bf16_t* q_hi, const bf16_t* q_lo, const bf16_t* k_hi, const bf16_t* k_lo,
                          const bf16_t* v_hi, const bf16_t* v_lo, const bf16_t* o_hi, const bf16_t* o_lo, const bf16_t* do_hi,
                          const bf16_t* do_lo, const float* lse2, float* delta, bf16_t* g_hi, bf16_t* g_lo, int B, int H, int S,
-                         float qscale, int terms, hipStream_t s) {
+                         float qscale, int terms, int grad_terms, hipStream_t s) {
   AWT_REQUIRE(B > 0 && H > 0 && S > 0, AWT_ERR_INVALID, "attention_bwd: bad shape");
+  AWT_REQUIRE(grad_terms == terms || (terms == 3 && grad_terms == 1), AWT_ERR_INVALID, "attention_bwd: grad_terms must equal terms, or be 1 with terms 3");
   AWT_REQUIRE(terms == 1 || terms == 3, AWT_ERR_INVALID, "attention_bwd: terms must be 1 or 3");
   AWT_REQUIRE(q_hi && k_hi && v_hi && o_hi && do_hi && lse2 && delta && g_hi, AWT_ERR_INVALID, "attention_bwd: null argument");
   AWT_REQUIRE(terms == 1 || (q_lo && k_lo && v_lo && o_lo && do_lo && g_lo), AWT_ERR_INVALID, "attention_bwd: lo planes required");
@@ -304,7 +307,7 @@ int launch_attention_bwd(awt_ctx* c, const bf16_t* q_hi, const bf16_t* q_lo, con
                      terms == 3 ? o_lo : nullptr, delta, B, H, S);
   AWT_HIP_CHECK(hipGetLastError());
   BwdArgs a{q_hi, q_lo, k_hi, k_lo, v_hi, v_lo, do_hi, do_lo, lse2, delta, g_hi, terms == 3 ? g_lo : nullptr, B, H, S, qscale};
-  int rc = terms == 3 ? launch_mode<3, MODE_DQ>(a, s) : launch_mode<1, MODE_DQ>(a, s);
+  int rc = terms == 1 ? launch_mode<1, MODE_DQ, 1>(a, s) : (grad_terms == 3 ? launch_mode<3, MODE_DQ, 3>(a, s) : launch_mode<3, MODE_DQ, 1>(a, s));
   if (rc) return rc;
-  return terms == 3 ? launch_mode<3, MODE_DKV>(a, s) : launch_mode<1, MODE_DKV>(a, s);
+  return terms == 1 ? launch_mode<1, MODE_DKV, 1>(a, s) : (grad_terms == 3 ? launch_mode<3, MODE_DKV, 3>(a, s) : launch_mode<3, MODE_DKV, 1>(a, s));
 }

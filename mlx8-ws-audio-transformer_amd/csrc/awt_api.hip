@@ -429,6 +429,8 @@ extern "C" int awt_encoder_create(awt_ctx* c, const awt_encoder_cfg* cfg, awt_en
   AWT_REQUIRE(cfg->n_mels > 0 && cfg->n_mels % 8 == 0 && cfg->n_mels <= 128, AWT_ERR_INVALID, "encoder_create: n_mels must be a multiple of 8, <= 128");
   AWT_REQUIRE(cfg->n_layers > 0 && cfg->n_ctx > 0, AWT_ERR_INVALID, "encoder_create: n_layers and n_ctx must be positive");
   AWT_REQUIRE(cfg->mfma_terms == 1 || cfg->mfma_terms == 3, AWT_ERR_INVALID, "encoder_create: mfma_terms must be 1 or 3");
+  AWT_REQUIRE(cfg->backward_terms == 0 || cfg->backward_terms == cfg->mfma_terms || (cfg->backward_terms == 1 && cfg->mfma_terms == 3), AWT_ERR_INVALID,
+              "encoder_create: backward_terms must be 0 (= mfma_terms), mfma_terms, or 1");
   AWT_REQUIRE(cfg->lora_rank >= 0 && cfg->lora_rank <= 32, AWT_ERR_INVALID, "encoder_create: lora_rank must be in 0..32");
   AWT_REQUIRE(cfg->lora_rank == 0 || cfg->lora_targets != 0, AWT_ERR_INVALID, "encoder_create: lora_rank > 0 needs lora_targets");
   AWT_REQUIRE(!cfg->training || (cfg->lora_rank > 0 && !(cfg->lora_targets & (AWT_LORA_OUT | AWT_LORA_FC1 | AWT_LORA_FC2))), AWT_ERR_INVALID,
@@ -699,6 +701,8 @@ extern "C" int awt_encoder_backward(awt_encoder* e, const float* d_hidden, int B
   hipStream_t s = (hipStream_t)stream;
   const awt_encoder_cfg& c = e->cfg;
   const int S = c.n_ctx, d = c.d_model, f = c.ffn_dim, H = c.n_heads, terms = c.mfma_terms, r = c.lora_rank;
+  // products of the gradient contractions: the forward's (default), or one bf16 product per fragment pair (opt-in fast backward)
+  const int gterms = c.backward_terms ? c.backward_terms : terms;
   const int M = B * S;
   const int64_t plane = (int64_t)M * d;
   const float lscale = c.lora_alpha / (float)r;
@@ -718,12 +722,12 @@ extern "C" int awt_encoder_backward(awt_encoder* e, const float* d_hidden, int B
     {
       GemmSeg sg = seg_plain(w.dxp[0], w.dxp[1], d, L.fc2T, 0, d, M);
       GemmOut o{}; o.hi = w.dpre[0]; o.lo = w.dpre[1]; o.ldo = f; o.n_valid = f; o.pre_hi = b.pre[0]; o.pre_lo = b.pre[1];
-      rc = launch_gemm(e->ctx, M, f, &sg, 1, terms, EPI_BF16_DGELU, o, s); if (rc) return rc;
+      rc = launch_gemm(e->ctx, M, f, &sg, 1, gterms, EPI_BF16_DGELU, o, s); if (rc) return rc;
     }
     {
       GemmSeg sg = seg_plain(w.dpre[0], w.dpre[1], f, L.fc1T, 0, f, M);
       GemmOut o{}; o.f32 = w.dln; o.ldo = d; o.n_valid = d;
-      rc = launch_gemm(e->ctx, M, d, &sg, 1, terms, EPI_F32, o, s); if (rc) return rc;
+      rc = launch_gemm(e->ctx, M, d, &sg, 1, gterms, EPI_F32, o, s); if (rc) return rc;
     }
     rc = launch_layernorm_bwd(e->ctx, w.dln, b.x_mid, L.ln2_g, dx, M, d, 1e-5f, dx_other, w.dxp[0], w.dxp[1], s); if (rc) return rc;
     std::swap(dx, dx_other);   // dx = d(loss)/d(x_mid)
@@ -731,18 +735,18 @@ extern "C" int awt_encoder_backward(awt_encoder* e, const float* d_hidden, int B
     {
       GemmSeg sg = seg_plain(w.dxp[0], w.dxp[1], d, L.outT, 0, d, M);
       GemmOut o{}; o.hi = w.datt[0]; o.lo = w.datt[1]; o.ldo = d; o.n_valid = d; o.scale = 1.0f;
-      rc = launch_gemm(e->ctx, M, d, &sg, 1, terms, EPI_BF16, o, s); if (rc) return rc;
+      rc = launch_gemm(e->ctx, M, d, &sg, 1, gterms, EPI_BF16, o, s); if (rc) return rc;
     }
     rc = launch_attention_bwd(e->ctx, b.qkv[0], b.qkv[1], b.qkv[0] + plane, b.qkv[1] ? b.qkv[1] + plane : nullptr, b.qkv[0] + 2 * plane,
                               b.qkv[1] ? b.qkv[1] + 2 * plane : nullptr, b.att[0], b.att[1], w.datt[0], w.datt[1], b.lse, w.delta,
-                              w.dqkv[0], w.dqkv[1], B, H, S, 0.125f, terms, s);
+                              w.dqkv[0], w.dqkv[1], B, H, S, 0.125f, terms, gterms, s);
     if (rc) return rc;
     // ---- adapter gradients.  Forward: u = lscale * ln1 A^T (saved), y = ln1 W^T + b + u B^T.
     //      dB = dy^T u ; du = dy B ; dA = lscale * du^T ln1
     {
       GemmSeg sg = seg_plain(w.dqkv[0], w.dqkv[1], 3 * d, L.lq.bT, 0, 3 * d, M);
       GemmOut o{}; o.hi = w.du[0]; o.lo = w.du[1]; o.ldo = L.lq.kp; o.n_valid = L.lq.kp; o.scale = 1.0f;
-      rc = launch_gemm(e->ctx, M, 128, &sg, 1, terms, EPI_BF16, o, s); if (rc) return rc;
+      rc = launch_gemm(e->ctx, M, 128, &sg, 1, gterms, EPI_BF16, o, s); if (rc) return rc;
     }
     float* g = lora_grads + (size_t)li * per_layer;
     int slot_out = 0;
@@ -765,7 +769,7 @@ extern "C" int awt_encoder_backward(awt_encoder* e, const float* d_hidden, int B
       sg[0] = seg_plain(w.dqkv[0], w.dqkv[1], 3 * d, L.qkvT, 0, 3 * d, M);
       sg[1] = seg_plain(w.du[0], w.du[1], L.lq.kp, L.lq.aT, 0, L.lq.kp, M);
       GemmOut o{}; o.f32 = w.dln; o.ldo = d; o.n_valid = d;
-      rc = launch_gemm(e->ctx, M, d, sg, 2, terms, EPI_F32, o, s); if (rc) return rc;
+      rc = launch_gemm(e->ctx, M, d, sg, 2, gterms, EPI_F32, o, s); if (rc) return rc;
     }
     rc = launch_layernorm_bwd(e->ctx, w.dln, b.x_in, L.ln1_g, dx, M, d, 1e-5f, dx_other, w.dxp[0], w.dxp[1], s); if (rc) return rc;
     std::swap(dx, dx_other);

@@ -175,7 +175,7 @@ void awt_gemm_force_tile(int t);  // 0 auto, 64 / 128 / 256: tuning / tests (awt
 int launch_attention_bwd(awt_ctx* c, const bf16_t* q_hi, const bf16_t* q_lo, const bf16_t* k_hi, const bf16_t* k_lo,
                          const bf16_t* v_hi, const bf16_t* v_lo, const bf16_t* o_hi, const bf16_t* o_lo, const bf16_t* do_hi,
                          const bf16_t* do_lo, const float* lse2, float* delta, bf16_t* g_hi, bf16_t* g_lo, int B, int H, int S,
-                         float qscale, int terms, hipStream_t s);
+                         float qscale, int terms, int grad_terms, hipStream_t s);
 // dx = dres + LayerNorm_backward(dy; x, gamma)  (fp32), plus bf16 hi/lo planes of dx for the next GEMM; dres may be null
 int launch_layernorm_bwd(awt_ctx* c, const float* dy, const float* x, const float* gamma, const float* dres, int M, int d, float eps,
                          float* dx, bf16_t* dx_hi, bf16_t* dx_lo, hipStream_t s);

@@ -92,8 +92,11 @@ def _attach(root: nn.Module, dotted: str, p: nn.Parameter) -> None:
 class NativeWhisperEncoder(nn.Module):
     def __init__(self, cfg: EncoderConfig, precision: str = "bf16x3", lora: Optional[LoraSpec] = None,
                  device: str = "cuda", chunk_clips: int = 0, seed: Optional[int] = 0, init_profile: str = "hf",
-                 trainable: bool = False):
+                 trainable: bool = False, backward_precision: Optional[str] = None):
         super().__init__()
+        if backward_precision not in (None, precision, "bf16"):
+            raise ValueError("backward_precision must be None (= precision) or 'bf16'")
+        self.backward_precision = backward_precision
         if precision not in PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(PRECISIONS)}")
         if cfg.head_dim != 64:
@@ -145,7 +148,7 @@ class NativeWhisperEncoder(nn.Module):
         cfg = _lib.EncoderCfg(self.cfg.d_model, self.cfg.layers, self.cfg.heads, self.cfg.ffn, self.cfg.n_mels,
                               self.cfg.max_source_positions, PRECISIONS[self.precision],
                               self.lora.r if self.lora else 0, float(self.lora.alpha) if self.lora else 0.0, bits, self._chunk,
-                              1 if self.trainable else 0)
+                              1 if self.trainable else 0, PRECISIONS[self.backward_precision] if self.backward_precision else 0)
         out = C.c_void_p()
         with torch.cuda.device(self.device):
             _lib.check(L.awt_encoder_create(_lib.ctx(self.device), C.byref(cfg), C.byref(out)))

@@ -155,14 +155,15 @@ class WhisperLoRAModel(nn.Module):
 
     def __init__(self, cfg: EncoderConfig, lora: LoraSpec, precision: str = "bf16x3", device: str = "cuda", decoder_layers: Optional[int] = None,
                  seed: int = 0, vocab: int = WHISPER_VOCAB, decoder_autocast: Optional[torch.dtype] = None, native_cross_kv: bool = True,
-                 max_target_positions: int = 448):
+                 max_target_positions: int = 448, backward_precision: Optional[str] = None):
         super().__init__()
         # the decoder is stock PyTorch (scope row "next"): fp32 like the reference (fp16=False, fineTune.py:170) unless
         # decoder_autocast=torch.bfloat16 asks torch to run its matmuls in bf16
         self.decoder_autocast = decoder_autocast
         self.native_cross_kv = native_cross_kv   # False: every decoder matmul on torch (the pre-fusion path, kept for A/B tests)
         self.precision = precision
-        self.encoder = NativeWhisperEncoder(cfg, precision=precision, lora=lora, device=device, seed=seed, trainable=True)
+        self.encoder = NativeWhisperEncoder(cfg, precision=precision, lora=lora, device=device, seed=seed, trainable=True,
+                                            backward_precision=backward_precision)
         torch.manual_seed(seed)
         self.decoder = WhisperDecoder(cfg.d_model, decoder_layers or cfg.layers, cfg.heads, cfg.ffn, vocab, max_target_positions).to(device)
         for p in self.decoder.parameters():

@@ -100,3 +100,26 @@ def test_backward_is_bit_identical_under_every_gemm_tiling():
     assert float(grads[0].abs().max()) > 0
     for g in grads[1:]:
         assert torch.equal(g, grads[0])
+
+
+def test_bf16_backward_option_stays_close_to_the_exact_backward():
+    """backward_precision="bf16": dp / dq / dk / dv and the backward GEMMs use one bf16 product per fragment pair (scores are
+    still recomputed in split-bf16).  The adapter gradients must stay within mixed-precision distance of the default."""
+    from mlx8_ws_audio_transformer_amd.encoder import NativeWhisperEncoder
+    cfg = wts.config("tiny", True)
+    spec = wts.LoraSpec(r=8, alpha=16.0, targets=("q_proj", "v_proj"))
+    LW = wts.init_lora_weights(cfg, spec, 0, zero_b=False)
+    mel = torch.from_numpy(oracle_mel.whisper_logmel(piano_clips_f32(2), n_samples=cfg.n_frames * 160)).cuda()
+    grads, outs = {}, {}
+    for bp in (None, "bf16"):
+        enc = NativeWhisperEncoder(cfg, precision="bf16x3", lora=spec, trainable=True, seed=0, init_profile="test", backward_precision=bp)
+        enc.load_state_dict({k: torch.from_numpy(v) for k, v in LW.items()}, strict=False)
+        out = enc(mel).last_hidden_state
+        (out * out).sum().backward()
+        outs[bp] = out.detach().clone()
+        grads[bp] = torch.cat([p.grad.flatten() for n, p in enc.named_parameters() if "lora_" in n])
+    assert torch.equal(outs[None], outs["bf16"])                       # the forward is untouched
+    rel = float((grads["bf16"] - grads[None]).norm() / grads[None].norm())
+    assert 1e-5 < rel < 2e-2, rel
+    with pytest.raises(ValueError):
+        NativeWhisperEncoder(cfg, precision="bf16x3", lora=spec, trainable=True, backward_precision="fp8")
