@@ -95,11 +95,11 @@ int awt_prepare_waveform(awt_ctx* c, const void* pcm, int pcm_is_i16, int channe
  * -> HF:models/whisper/modeling_whisper.py:592-646 (+ :379-413, :284-356, :215-238).
  */
 typedef struct awt_encoder_cfg {
-  int32_t d_model;          /* 384 tiny, 512 base, 768 small; multiple of 128                              */
+  int32_t d_model;          /* 384 tiny, 512 base, 768 small, 1024 medium, 1280 large; multiple of 128, <= 1280 */
   int32_t n_layers;
   int32_t n_heads;          /* head_dim = d_model / n_heads must be 64                                     */
   int32_t ffn_dim;          /* multiple of 128                                                             */
-  int32_t n_mels;           /* 80                                                                          */
+  int32_t n_mels;           /* 80 (tiny .. large-v2) or 128 (large-v3); multiple of 8, <= 128              */
   int32_t n_ctx;            /* S = max_source_positions: 1500 (reference) or 200 (trimmed); mel T = 2*S    */
   int32_t mfma_terms;       /* 1: bf16 operands (fast; ~4e-3 rel-L2 vs fp32); 3: split-bf16 hi+lo operands,
                                three MFMA products per fragment pair (meets the 1e-3 parity bound)         */
