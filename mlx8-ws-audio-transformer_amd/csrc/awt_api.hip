@@ -423,7 +423,6 @@ int copy_f32(float* dst, const float* src, size_t n, hipStream_t s) {
 extern "C" int awt_encoder_create(awt_ctx* c, const awt_encoder_cfg* cfg, awt_encoder** out) {
   AWT_REQUIRE(c && cfg && out, AWT_ERR_INVALID, "encoder_create: null argument");
   AWT_REQUIRE(cfg->d_model > 0 && cfg->d_model % 128 == 0 && cfg->d_model <= 1280, AWT_ERR_INVALID, "encoder_create: d_model must be a multiple of 128, <= 1280");
-  AWT_REQUIRE(!cfg->training || cfg->d_model <= 1024, AWT_ERR_INVALID, "encoder_create: training needs d_model <= 1024 (adapter-gradient reduction)");
   AWT_REQUIRE(cfg->n_heads > 0 && cfg->d_model == cfg->n_heads * 64, AWT_ERR_INVALID, "encoder_create: head_dim (d_model / n_heads) must be 64");
   AWT_REQUIRE(cfg->ffn_dim > 0 && cfg->ffn_dim % 128 == 0, AWT_ERR_INVALID, "encoder_create: ffn_dim must be a multiple of 128");
   AWT_REQUIRE(cfg->n_mels > 0 && cfg->n_mels % 8 == 0 && cfg->n_mels <= 128, AWT_ERR_INVALID, "encoder_create: n_mels must be a multiple of 8, <= 128");

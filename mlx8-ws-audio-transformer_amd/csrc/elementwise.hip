@@ -356,11 +356,12 @@ int launch_pack_weight_t(awt_ctx* c, const float* src, int N, int C, int64_t ld,
 
 size_t outer_reduce_partial_bytes(int M, int r, int ny) {
   const int R = r <= 8 ? 8 : (r <= 16 ? 16 : 32);
+  ny = ny < 1024 ? ny : 1024;   // wider blocks are reduced in 1024-column chunks
   const int nslab = (M + kOrRows - 1) / kOrRows;
   return (size_t)(nslab < kOrMaxBlocks ? nslab : kOrMaxBlocks) * R * ny * sizeof(float);
 }
 
-int launch_outer_reduce(awt_ctx* c, const bf16_t* x_hi, const bf16_t* x_lo, int64_t ldx, int xcol, int r, const bf16_t* y_hi,
+static int launch_outer_reduce_1(awt_ctx* c, const bf16_t* x_hi, const bf16_t* x_lo, int64_t ldx, int xcol, int r, const bf16_t* y_hi,
                         const bf16_t* y_lo, int64_t ldy, int ycol, int ny, int M, float scale, float* out, int64_t sj, int64_t sn,
                         float* partial, size_t partial_bytes, hipStream_t s) {
   AWT_REQUIRE(x_hi && y_hi && out && partial && r > 0 && r <= 32 && ny > 0 && ny % 4 == 0 && ny <= 1024, AWT_ERR_INVALID, "outer_reduce: bad shape");
@@ -378,5 +379,18 @@ int launch_outer_reduce(awt_ctx* c, const bf16_t* x_hi, const bf16_t* x_lo, int6
   AWT_HIP_CHECK(hipGetLastError());
   hipLaunchKernelGGL(outer_reduce_final_kernel, dim3((r * ny + 255) / 256), dim3(256), 0, s, partial, nslab, R, r, ny, scale, out, sj, sn);
   AWT_HIP_CHECK(hipGetLastError());
+  return AWT_OK;
+}
+
+// Y blocks wider than the kernel's 1024 columns (256 threads x 4) are reduced in column chunks (Whisper large: d = 1280)
+int launch_outer_reduce(awt_ctx* c, const bf16_t* x_hi, const bf16_t* x_lo, int64_t ldx, int xcol, int r, const bf16_t* y_hi,
+                        const bf16_t* y_lo, int64_t ldy, int ycol, int ny, int M, float scale, float* out, int64_t sj, int64_t sn,
+                        float* partial, size_t partial_bytes, hipStream_t s) {
+  for (int n0 = 0; n0 < ny; n0 += 1024) {
+    const int nc = ny - n0 < 1024 ? ny - n0 : 1024;
+    int rc = launch_outer_reduce_1(c, x_hi, x_lo, ldx, xcol, r, y_hi, y_lo, ldy, ycol + n0, nc, M, scale, out + (int64_t)n0 * sn, sj, sn,
+                                   partial, partial_bytes, s);
+    if (rc) return rc;
+  }
   return AWT_OK;
 }

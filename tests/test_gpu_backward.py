@@ -123,3 +123,25 @@ def test_bf16_backward_option_stays_close_to_the_exact_backward():
     assert 1e-5 < rel < 2e-2, rel
     with pytest.raises(ValueError):
         NativeWhisperEncoder(cfg, precision="bf16x3", lora=spec, trainable=True, backward_precision="fp8")
+
+
+def test_lora_gradients_at_large_width():
+    """d_model 1280 (Whisper large): the adapter-gradient reduction runs in 1024-column chunks."""
+    from mlx8_ws_audio_transformer_amd.encoder import NativeWhisperEncoder
+    cfg = wts.EncoderConfig(1280, 2, 20, 5120, 80, 200, "large-2layer-trimmed")
+    spec = wts.LoraSpec(r=8, alpha=16.0, targets=("q_proj", "v_proj"))
+    W = wts.init_encoder_weights(cfg, 0, "test")
+    LW = wts.init_lora_weights(cfg, spec, 0, zero_b=False)
+    mel = oracle_mel.whisper_logmel(piano_clips_f32(1), n_samples=cfg.n_frames * 160)
+    dout = (wts.unit_variates("dout", cfg.max_source_positions * cfg.d_model, 5).reshape(1, cfg.max_source_positions, cfg.d_model)
+            / np.sqrt(cfg.max_source_positions)).astype(np.float32)
+    _, ref_g = _oracle_grads(W, LW, mel, cfg, spec, dout)
+    enc = NativeWhisperEncoder(cfg, precision="bf16x3", lora=spec, trainable=True, seed=0, init_profile="test")
+    enc.load_state_dict({k: torch.from_numpy(v) for k, v in {**W, **LW}.items()})
+    out = enc(torch.from_numpy(mel).cuda()).last_hidden_state
+    (out * torch.from_numpy(dout).cuda()).sum().backward()
+    for name, p in enc.named_parameters():
+        if "lora_" in name:
+            ref = ref_g[name]
+            err = float(np.abs(p.grad.cpu().numpy() - ref).max()) / max(float(np.abs(ref).max()), 1e-12)
+            assert err < 1e-3, (name, err)
