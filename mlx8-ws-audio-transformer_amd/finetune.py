@@ -294,11 +294,16 @@ class Seq2SeqTrainer:
         self.log_history: List[Dict[str, float]] = []
         self.global_step = 0
 
-    def training_step(self, batch: Dict[str, torch.Tensor]) -> float:
-        """forward + backward + ONE all-reduce of the flat adapter-gradient buffer + AdamW."""
+    def training_step(self, batch) -> float:
+        """One optimizer step: forward + backward over `gradient_accumulation_steps` micro-batches (a single dict, or a list
+        of that many dicts), ONE all-reduce of the flat adapter-gradient buffer, clipping, AdamW, schedule."""
         dev = self.model.encoder.device
-        out = self.model(input_features=batch["input_features"].to(dev), labels=batch["labels"].to(dev))
-        (out.loss / self.args.gradient_accumulation_steps).backward()
+        micro = batch if isinstance(batch, (list, tuple)) else [batch]
+        total = 0.0
+        for mb in micro:
+            out = self.model(input_features=mb["input_features"].to(dev), labels=mb["labels"].to(dev))
+            (out.loss / len(micro)).backward()              # adapter .grad accumulates across micro-batches
+            total += float(out.loss.detach())
         self.bucket.allreduce_mean()
         if self.args.max_grad_norm and self.args.max_grad_norm > 0:
             torch.nn.utils.clip_grad_norm_(self.bucket.params, self.args.max_grad_norm)
@@ -306,7 +311,7 @@ class Seq2SeqTrainer:
         self.scheduler.step()
         self.optimizer.zero_grad(set_to_none=True)
         self.global_step += 1
-        return float(out.loss.detach())
+        return total / len(micro)
 
     def _batches(self):
         import torch.distributed as dist
@@ -369,7 +374,7 @@ class Seq2SeqTrainer:
         best, best_state = None, None
         it = self._batches()
         for _ in range(self.args.max_steps):
-            loss = self.training_step(next(it))
+            loss = self.training_step([next(it) for _ in range(max(1, self.args.gradient_accumulation_steps))])
             if self.global_step % max(1, self.args.logging_steps) == 0 or self.global_step == 1:
                 self.log_history.append({"step": self.global_step, "loss": loss, "lr": self.scheduler.get_last_lr()[0]})
             if do_eval and self.global_step % self.args.eval_steps == 0:

@@ -139,3 +139,31 @@ def test_evaluate_with_generate_and_wer():
     assert m["eval_loss"] > 0
     # clip 0 is decoded exactly (0 errors of 7 words), clip 1 shares no word with its reference (7 errors of 7)
     assert abs(m["eval_wer"] - 50.0) < 1e-6, m
+
+
+def test_gradient_accumulation_equals_one_big_batch():
+    """gradient_accumulation_steps = 2 over two half batches takes the same optimizer step as one full batch
+    (mean-of-means = mean here: equal micro-batch sizes and the same number of label tokens per clip)."""
+    from mlx8_ws_audio_transformer_amd.finetune import Seq2SeqTrainer, Seq2SeqTrainingArguments
+    cfg = wts.config("mini", True)
+    b = _batch(cfg, 4)
+    b["labels"] = b["labels"].clone()
+    b["labels"][b["labels"] == -100] = 7                      # same token count in every row: the two loss means weigh equally
+    steps = {}
+    for ga in (1, 2):
+        model = _model(cfg)
+        for p in model.lora_parameters():
+            if p.shape[1] == 8:
+                with torch.no_grad():
+                    p.copy_(torch.from_numpy(0.05 * wts.unit_variates("ga", p.numel(), 1).reshape(p.shape).astype(np.float32)))
+        args = Seq2SeqTrainingArguments(per_device_train_batch_size=4 // ga, gradient_accumulation_steps=ga, learning_rate=1e-2, warmup_steps=0,
+                                        max_steps=1, predict_with_generate=False, max_grad_norm=0.0)
+        tr = Seq2SeqTrainer(args=args, model=model)
+        before = torch.cat([p.detach().flatten().clone() for p in model.lora_parameters()])
+        if ga == 1:
+            tr.training_step(b)
+        else:
+            tr.training_step([{k: v[:2] for k, v in b.items()}, {k: v[2:] for k, v in b.items()}])
+        steps[ga] = torch.cat([p.detach().flatten() for p in model.lora_parameters()]) - before
+    assert float(steps[1].abs().max()) > 0
+    assert float((steps[1] - steps[2]).abs().max()) < 2e-3 * float(steps[1].abs().max())
