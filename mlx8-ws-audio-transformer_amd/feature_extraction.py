@@ -86,7 +86,9 @@ class WhisperFeatureExtractor:
     def __call__(self, raw_speech, truncation: bool = True, pad_to_multiple_of=None, return_tensors: Optional[str] = None,
                  return_attention_mask: Optional[bool] = None, padding: Optional[str] = "max_length",
                  max_length: Optional[int] = None, sampling_rate: Optional[int] = None, do_normalize: Optional[bool] = None,
-                 device: Optional[str] = None, **kwargs) -> BatchFeature:
+                 device: Optional[str] = None, keep_on_device: bool = False, **kwargs) -> BatchFeature:
+        """`keep_on_device=True` (with return_tensors="pt") leaves `input_features` in HBM instead of copying it to the host as the
+        reference's extractor does: the 960 KB per clip then never cross PCIe on their way to the encoder."""
         if sampling_rate is not None and sampling_rate != self.sampling_rate:
             raise ValueError(
                 f"The model corresponding to this feature extractor: {self.__class__.__name__} was trained using a"
@@ -112,7 +114,9 @@ class WhisperFeatureExtractor:
         pcm = host.to(dev, non_blocking=True)
         feats = logmel_whisper_device(pcm, torch.from_numpy(lens), int(lens.max()), n_frames, n_mels=self.feature_size)
         out = BatchFeature()
-        feats_cpu = feats.cpu()  # the reference's extractor returns host arrays
+        if keep_on_device and return_tensors != "pt":
+            raise ValueError("keep_on_device needs return_tensors='pt'")
+        feats_cpu = feats if keep_on_device else feats.cpu()  # the reference's extractor returns host arrays
         want_mask = self.return_attention_mask if return_attention_mask is None else return_attention_mask
         if want_mask:
             mask = (np.arange(n_samples)[None, :] < lens[:, None]).astype(np.int32)[:, :: self.hop_length]

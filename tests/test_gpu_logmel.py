@@ -45,6 +45,15 @@ def test_int16_pcm_path_and_device_entry_point():
     np.testing.assert_allclose(out, ref, rtol=0, atol=MEL_TOL)
 
 
+def test_keep_on_device_returns_the_same_features_in_hbm(fe):
+    clips = piano_clips_f32(2)
+    host = fe(clips, sampling_rate=16000, return_tensors="pt")["input_features"]
+    dev = fe(clips, sampling_rate=16000, return_tensors="pt", keep_on_device=True)["input_features"]
+    assert dev.is_cuda and not host.is_cuda and torch.equal(dev.cpu(), host)
+    with pytest.raises(ValueError):
+        fe(clips, sampling_rate=16000, return_tensors="np", keep_on_device=True)
+
+
 def test_full_30s_clip_and_truncation(fe):
     x = np.concatenate([logmel_inputs()["tone"]] * 8)[:500000]   # longer than 30 s: truncated like the reference
     out = fe(x, sampling_rate=16000, return_tensors="np")["input_features"][0]
