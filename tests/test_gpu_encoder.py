@@ -212,3 +212,29 @@ def test_every_gemm_tiling_gives_the_same_bits(precision):
             assert torch.equal(enc2(mel2).last_hidden_state, ref)
         finally:
             _lib.tuning_set("gemm_tile", 0)
+
+
+def test_outlier_channels_keep_the_relative_error():
+    """Trained Whisper weights have a few very large LayerNorm gains / activation channels.  The split-bf16 operands are
+    floating point per element (relative 2^-17), so outliers do not change the RELATIVE error (rel-L2 ~5e-5), but the
+    absolute error of a channel grows with the gains on its path: with 30x gains on every LayerNorm (outputs up to |x| ~ 66)
+    the worst element is off by ~7e-3, where the reference's own fp32 arithmetic is off by 7e-4 from fp64 on the same
+    weights.  DESIGN.md "Numerics" states the absolute 1e-3 bound with that scope."""
+    cfg = wts.config("tiny", True)
+    W = wts.init_encoder_weights(cfg, 0, "test")
+    rng = np.random.default_rng(0)
+    for name in list(W):
+        if name.endswith("_layer_norm.weight") or name == "layer_norm.weight":
+            idx = rng.choice(cfg.d_model, 4, replace=False)
+            W[name] = W[name].copy(); W[name][idx] *= 30.0
+        if name.endswith("fc2.weight") or name.endswith("out_proj.weight"):
+            idx = rng.choice(W[name].shape[0], 2, replace=False)
+            W[name] = W[name].copy(); W[name][idx] *= 10.0      # rows feeding outlier residual channels
+    mel = _mel(cfg, 2)
+    enc = _native(cfg, "bf16x3")
+    enc.load_state_dict({k: torch.from_numpy(v) for k, v in W.items()})
+    out = enc(torch.from_numpy(mel).cuda()).last_hidden_state.cpu().numpy()
+    ref = oracle_enc.encoder_forward(W, mel, cfg.heads, dtype=torch.float64).numpy()
+    e = oracle_enc.error_norms(out, ref)
+    assert float(np.abs(ref).max()) > 30.0
+    assert e["rel_l2"] < 1e-4 and e["max_abs"] < 1.5e-2, e
