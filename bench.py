@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Throughput of the hot path: 4 s @ 16 kHz clips/sec through log-mel + Whisper-small encoder on N MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          # N > 1: this process starts N ranks itself (one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 One "step" = one pass of the hot path over one batch of synthetic clips per GPU: int16 PCM [B, 64000] already
@@ -10,32 +10,41 @@ all inside `awt_audio_encode` (libawt, hand-written HIP).  Reference semantics (
 zero-padded to 30 s and all 1500 positions are attended; weights are random-init of the Whisper-small
 architecture (no checkpoint offline).  Clips shard across ranks with no data-path collective (weak scaling).
 
+Workloads (--workload):
+  encode    (default, BASELINE.json's metric) the step above, K times over the same resident batch
+  sweep     BASELINE.json configs[4]: the seeded 10 000-clip piano-note set, pre-staged per rank as one int16 device tensor
+            (contiguous shard, dist.shard_range), walked once in batches of B incl. the short tail batch
+  finetune  configs[2]/[3]: one LoRA fine-tune step = log-mel + encoder fwd/bwd + decoder/CE + gradient exchange + AdamW
+  noop      launcher / rendezvous / timing / JSON rehearsal without touching the GPU (CPU test of the N > 1 plumbing)
+
 The JSON line carries, besides the driver's contract fields:
   roofline      the dominant kernel class (the MFMA GEMMs), timed live with HIP events on the launch stream;
                 achieved = algorithmic FLOP (2 M N K per launch) / event time, peak = dense bf16 MFMA peak
   cpu_baseline  oracle/ (CPU restatement of the reference) timed on this host's cores on a bounded sample (rank 0, N=1)
   parity        HIP outputs vs that oracle on the same sample
+  ranks         per-rank clips/s, the collective backend and the world size an all-reduce of ones actually returned
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_DENSE_TFLOPS = 2500.0   # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
-# operand + result bytes of the 50 GEMM launches of one step (Whisper-small, B = 64, bf16 hi + lo planes, fp32 residual):
+# operand + result bytes of the 50 GEMM launches of one step (Whisper-small, B = 64, two 2-byte operand planes, fp32 residual):
 # per layer qkv (295 + 885 MB), out (295 + 590), fc1 (295 + 1180), fc2 (1180 + 590) = 5.31 GB; conv stem 0.2 + 1.2 + 0.3 GB
 GEMM_ALGO_BYTES_PER_STEP = 12 * 5.31e9 + 1.7e9
 ENCODER_GFLOP_PER_CLIP = {("small", False): 344.16, ("small", True): 36.30, ("tiny", False): 36.94, ("tiny", True): 3.33,
                           ("base", False): 87.37}   # BASELINE.md §4
+PRECISIONS = ["bf16x3", "bf16"]
 
 
 def parse():
@@ -45,15 +54,15 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--model", default="small")
     ap.add_argument("--batch", type=int, default=64, help="clips per GPU per step")
-    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16"],
+    ap.add_argument("--precision", default="bf16x3", choices=PRECISIONS,
                     help="bf16x3 (default) meets the 1e-3 hidden-state bound; bf16 is the single-pass fast mode")
     ap.add_argument("--trimmed", action="store_true", help="T=400/S=200 mode (NOT reference-equivalent)")
     ap.add_argument("--chunk", type=int, default=0, help="clips per kernel wave inside the library (0 = default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fast-mode", action="store_true")
     ap.add_argument("--cpu-clips", type=int, default=8)
-    ap.add_argument("--workload", default="encode", choices=["encode", "finetune"],
-                    help="encode (default, the headline metric) or finetune: one LoRA step = fwd + bwd + all-reduce + AdamW")
+    ap.add_argument("--workload", default="encode", choices=["encode", "sweep", "finetune", "noop"])
+    ap.add_argument("--clips", type=int, default=10000, help="sweep workload: clips in the whole set (sharded over the ranks)")
     ap.add_argument("--lora-r", type=int, default=8)
     ap.add_argument("--decoder-dtype", default="fp32", choices=["fp32", "bf16"], help="finetune workload: dtype of the stock-PyTorch decoder")
     ap.add_argument("--backward-precision", default=None, choices=["bf16"],
@@ -63,10 +72,174 @@ def parse():
     return ap.parse_args()
 
 
-def finetune_main(a, rank, local_rank, world, dev):
+# ------------------------------------------------------------------------------------------------ launcher
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(a) -> int:
+    """`python bench.py --gpus N` without a torchrun wrapper: start N fresh rank processes (one per GPU) BEFORE this process
+    touches the GPU, wait for them, and return the worst exit code.  Rank 0's stdout (the JSON line) is this process'."""
+    import torch          # device_count() does not initialise the GPU on this image
+    if a.dist_backend == "nccl" and a.workload != "noop":
+        have = torch.cuda.device_count()
+        if have < a.gpus:
+            print(f"bench.py: --gpus {a.gpus} but only {have} GPU(s) are visible", file=sys.stderr)
+            return 2
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    procs = []
+    for r in range(a.gpus):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=e,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    worst = 0
+    deadline = time.time() + 3300
+    for p in procs:
+        try:
+            rc = p.wait(timeout=max(1.0, deadline - time.time()))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            rc = 124
+        worst = worst or rc
+        if rc:                                   # a dead rank leaves the others in a collective: end them
+            for q in procs:
+                if q.poll() is None:
+                    q.kill()
+    return worst
+
+
+class Ranks:
+    """RANK / LOCAL_RANK / WORLD_SIZE plumbing shared by every workload: process group, barrier + max-over-ranks timing,
+    per-rank gathers, and a check that the group really spans `--gpus` ranks."""
+
+    def __init__(self, a, need_gpu: bool = True):
+        import torch
+        self.torch = torch
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if self.world != a.gpus:
+            raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={self.world}")
+        self.backend = a.dist_backend if self.world > 1 else "none"
+        self.dev = None
+        if need_gpu:
+            if not torch.cuda.is_available():
+                raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+            self.dev = torch.device("cuda", self.local_rank if a.dist_backend == "nccl" else 0)
+            torch.cuda.set_device(self.dev)
+        self.collective_ranks = 1
+        if self.world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if a.dist_backend == "nccl":
+                dist.init_process_group("nccl", device_id=self.dev)
+            else:
+                dist.init_process_group("gloo")
+            ones = torch.ones(1, dtype=torch.float64, device=self.dev if (need_gpu and a.dist_backend == "nccl") else "cpu")
+            dist.all_reduce(ones)
+            self.collective_ranks = int(ones.item())
+            if self.collective_ranks != a.gpus:
+                raise SystemExit(f"the {a.dist_backend} group spans {self.collective_ranks} ranks, --gpus asked for {a.gpus}")
+
+    def sync(self):
+        if self.dev is not None:
+            self.torch.cuda.synchronize(self.dev)
+
+    def barrier(self):
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    def timed(self, fn, steps: int):
+        """barrier + synchronize on both sides of exactly `steps` calls of fn; returns (max-over-ranks seconds, this rank's
+        seconds, last result)."""
+        self.sync(); self.barrier(); self.sync()
+        t0 = time.perf_counter()
+        out = None
+        for _ in range(steps):
+            out = fn()
+        self.sync()
+        mine = time.perf_counter() - t0
+        self.barrier()
+        dt = time.perf_counter() - t0
+        return self.max(dt), mine, out
+
+    def _cpu_or_dev(self):
+        return self.dev if (self.dev is not None and self.backend == "nccl") else "cpu"
+
+    def max(self, x: float) -> float:
+        if self.world == 1:
+            return x
+        import torch.distributed as dist
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=self._cpu_or_dev())
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def gather(self, x: float):
+        """[x of rank 0, x of rank 1, ...] on every rank."""
+        if self.world == 1:
+            return [x]
+        import torch.distributed as dist
+        t = self.torch.zeros(self.world, dtype=self.torch.float64, device=self._cpu_or_dev())
+        t[self.rank] = x
+        dist.all_reduce(t)
+        return [float(v) for v in t.tolist()]
+
+    def describe(self, per_rank_units_per_s):
+        return {"world": self.world, "backend": {"nccl": "rccl (torch.distributed 'nccl')", "gloo": "gloo", "none": "none"}[self.backend],
+                "collective_ranks": self.collective_ranks, "rccl_ranks": self.collective_ranks if self.backend == "nccl" else 0,
+                "per_rank_clips_per_s": [round(v, 2) for v in per_rank_units_per_s]}
+
+    def finish(self):
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+
+
+def source_hash() -> str:
+    """sha256 over the HIP sources + headers: ties a committed rocprof summary to the build it was measured on."""
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "mlx8-ws-audio-transformer_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode()); h.update(open(os.path.join(csrc, name), "rb").read())
+    h.update(open(os.path.join(ROOT, "include", "awt.h"), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def device_info(torch, dev):
+    props = torch.cuda.get_device_properties(dev)
+    return {"name": props.name, "arch": getattr(props, "gcnArchName", ""), "compute_units": props.multi_processor_count,
+            "hbm_gib": round(props.total_memory / 2 ** 30, 1),
+            "note": "peaks used: 2.5 PFLOP/s dense bf16 MFMA, 8 TB/s HBM3E (MI355X_MICROARCH.md); the encoder runs at the "
+                    "1400 W package limit with sclk 1.9-2.1 GHz (DESIGN.md 4.2)"}
+
+
+# ------------------------------------------------------------------------------------------------ workloads
+def noop_main(a):
+    """No GPU: the launcher, the rendezvous, the barrier / max-over-ranks timing and the JSON assembly of the real workloads."""
+    R = Ranks(a, need_gpu=False)
+    dt, mine, _ = R.timed(lambda: time.sleep(0.001), a.steps)
+    rates = R.gather(a.batch * a.steps / mine)
+    if R.rank == 0:
+        print(json.dumps({"metric": "launcher rehearsal (no GPU work)", "value": round(a.batch * R.world * a.steps / dt, 2), "unit": "clips/s",
+                          "n_gpus": R.world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "none",
+                          "config": {"workload": "noop"}, "ranks": R.describe(rates)}))
+    R.finish()
+
+
+def finetune_main(a):
     """BASELINE.json configs[2]/[3]: Whisper-small + LoRA (q_proj, v_proj) fine-tune step, B clips per GPU, 12 label tokens,
-    one RCCL all-reduce of the flat adapter-gradient buffer per step.  Decoder + CE are stock PyTorch ops (scope row 'next')."""
-    import torch.distributed as dist
+    one in-place mean all-reduce of the flat adapter-gradient buffer per step (RCCL through libawt's communicator under the
+    nccl backend).  Decoder + CE are stock PyTorch ops (scope row 'next')."""
+    R = Ranks(a)
+    torch, dev, rank, world = R.torch, R.dev, R.rank, R.world
     from mlx8_ws_audio_transformer_amd import synth, weights as wts
     from mlx8_ws_audio_transformer_amd.feature_extraction import logmel_whisper_device
     from mlx8_ws_audio_transformer_amd.finetune import Seq2SeqTrainer, Seq2SeqTrainingArguments, WhisperLoRAModel
@@ -80,43 +253,77 @@ def finetune_main(a, rank, local_rank, world, dev):
     labels = torch.randint(0, 51864, (B, 12), generator=g); labels[:, 0] = 50258
     args = Seq2SeqTrainingArguments(per_device_train_batch_size=B, learning_rate=1e-5, max_steps=10 ** 6, predict_with_generate=False)
     tr = Seq2SeqTrainer(args=args, model=model)
+    state = {}
 
     def step():
         feats = logmel_whisper_device(pcm, n_frames=cfg.n_frames)       # mel is part of the step, as in the encode workload
-        return tr.training_step({"input_features": feats, "labels": labels})
+        state["loss"] = tr.training_step({"input_features": feats, "labels": labels})
 
     for _ in range(a.warmup):
         step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        loss = step()
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
+    dt, mine, _ = R.timed(step, a.steps)
+    rates = R.gather(B * a.steps / mine)
     if rank == 0:
         print(json.dumps({
             "metric": "4s@16kHz clips/sec through mel+Whisper-%s LoRA fine-tune step" % a.model, "value": round(B * world * a.steps / dt, 2),
             "unit": "clips/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "LoRA r=%d (q_proj, v_proj) fine-tune step: log-mel + encoder fwd/bwd (HIP) + decoder/CE (torch) + all-reduce + AdamW" % a.lora_r,
+            "config": {"workload": "LoRA r=%d (q_proj, v_proj) fine-tune step: log-mel + encoder fwd/bwd (HIP) + decoder/CE (torch) + gradient exchange + AdamW" % a.lora_r,
                        "clips_per_gpu_per_step": B, "global_batch": B * world, "precision": a.precision, "label_tokens": 12, "decoder_dtype": a.decoder_dtype,
                        "backward_precision": a.backward_precision or a.precision,
-                       "adapter_grad_elems": tr.bucket.numel, "parallelism": "dp%d, one RCCL all-reduce of %.2f MB per step" % (world, tr.bucket.numel * 4 / 1e6)},
-            "last_loss": loss}))
-    if world > 1:
-        dist.destroy_process_group()
+                       "adapter_grad_elems": tr.bucket.numel, "gradient_exchange": tr.exchange,
+                       "parallelism": "dp%d, one in-place mean all-reduce of %.2f MB per step" % (world, tr.bucket.numel * 4 / 1e6)},
+            "ranks": R.describe(rates), "last_loss": state["loss"]}))
+    R.finish()
 
 
-def sample_power(step, dev, steps=40):
+def sweep_main(a):
+    """BASELINE.json configs[4]: the whole seeded clip set, end to end, once.  Every rank pre-stages its contiguous shard as one
+    int16 device tensor and walks it in batches of B (the last one short); value = clips of the whole set / max-over-ranks time."""
+    from mlx8_ws_audio_transformer_amd import sweep
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    t0 = time.perf_counter()
+    shard, first = sweep.stage_shard(a.clips, rank, world, seed=1234)     # host synthesis (forks a pool): before the GPU is touched
+    t_synth = time.perf_counter() - t0
+    R = Ranks(a)
+    torch, dev = R.torch, R.dev
+    from mlx8_ws_audio_transformer_amd import weights as wts
+    from mlx8_ws_audio_transformer_amd.encoder import NativeWhisperEncoder
+    cfg = wts.config(a.model, a.trimmed)
+    pcm = torch.from_numpy(shard).to(dev)
+    enc = NativeWhisperEncoder(cfg, precision=a.precision, device=str(dev), chunk_clips=a.chunk, seed=0, init_profile="hf").eval()
+    for _ in range(max(1, a.warmup)):
+        enc.encode_pcm(pcm[: a.batch])
+    check = torch.zeros((), dtype=torch.float64, device=dev)
+
+    def sink(b0, hidden):
+        check.add_(hidden.sum(dtype=torch.float64))     # every hidden state is consumed once: the batches are really computed
+
+    dt, mine, n_local = R.timed(lambda: sweep.encode_sweep(enc, pcm, a.batch, sink), 1)
+    rates = R.gather(n_local / mine)
+    checks = R.gather(float(check.item()))
+    nb = -(-pcm.shape[0] // a.batch)
+    if R.rank == 0:
+        value = a.clips / dt
+        gf = ENCODER_GFLOP_PER_CLIP.get((a.model, a.trimmed))
+        print(json.dumps({
+            "metric": "4s@16kHz clips/sec through mel+Whisper-%s encoder, %d-clip sweep" % (a.model, a.clips), "value": round(value, 2),
+            "unit": "clips/s", "n_gpus": R.world, "steps": nb, "warmup": max(1, a.warmup), "ms_per_step": round(dt / nb * 1e3, 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic", "device": device_info(torch, dev),
+            "config": {"workload": "%d seeded piano-note clips (synth.py, seed 1234; distributions of AB/synthDataset.py:46-76) pre-staged as int16 in HBM, "
+                                   "contiguous shard per rank, batches of %d incl. the tail batch -> log-mel -> Whisper-%s encoder -> hidden states" % (a.clips, a.batch, a.model),
+                       "mode": "trimmed (NOT reference-equivalent)" if a.trimmed else "parity (clip zero-padded to 30 s, as the reference computes)",
+                       "clips_total": a.clips, "clips_this_rank": int(pcm.shape[0]), "batches_this_rank": nb, "tail_batch": int(pcm.shape[0] % a.batch),
+                       "precision": a.precision, "parallelism": "dp%d (contiguous clip shards, no data-path collective)" % R.world},
+            "seconds_whole_set": round(dt, 3), "host_synthesis_s": round(t_synth, 2),
+            "end_to_end_frac_of_mfma_peak": round(value * gf / 1e3 / PEAK_BF16_DENSE_TFLOPS / R.world, 4) if gf else None,
+            "hidden_checksum_per_rank": checks, "ranks": R.describe(rates)}))
+    R.finish()
+
+
+def sample_power(torch, step, dev, steps=40):
     """Queues `steps` more (untimed) steps and reads rocm-smi while the GPU works through them.  None if rocm-smi is missing."""
     import re
-    import subprocess
     try:
         for _ in range(steps):
             step()
@@ -133,49 +340,46 @@ def sample_power(step, dev, steps=40):
         return None
 
 
-def timed_steps(enc, pcm, steps, world, dev):
-    """barrier + synchronize on both sides, returns max-over-ranks seconds for exactly `steps` steps."""
-    import torch.distributed as dist
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    out = None
-    for _ in range(steps):
-        out = enc.encode_pcm(pcm)
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    return dt, out
+def cpu_baseline_and_parity(a, torch, cfg, enc, pcm, pcm_host, out_first):
+    """The oracle (CPU restatement of the reference path) on this host's cores: 1 warm-up + 3 timed passes over a bounded
+    sample, median, for mel alone, encoder alone and end to end; then HIP vs oracle on the same clips."""
+    import numpy as np
+    from mlx8_ws_audio_transformer_amd import synth, weights as wts
+    from oracle import encoder as oenc, logmel as omel
+    n = min(a.cpu_clips, pcm.shape[0])
+    avail = len(os.sched_getaffinity(0))
+    cap = int(os.environ.get("AWT_CPU_THREADS", "16"))     # the GPU box gives one GPU's share of the host: 16 cores
+    ncpu = min(avail, cap)
+    torch.set_num_threads(ncpu)
+    W = wts.init_encoder_weights(cfg, 0, "hf")
+    clips_f32 = [synth.pcm_i16_to_f32(c) for c in pcm_host[:n]]
+    t_mel, t_enc = [], []
+    for it in range(4):                                     # pass 0 is the warm-up
+        t0 = time.perf_counter()
+        mel = omel.whisper_logmel(clips_f32, n_samples=cfg.n_frames * 160)
+        t1 = time.perf_counter()
+        with torch.no_grad():
+            ref = oenc.encoder_forward(W, mel, cfg.heads)
+        t2 = time.perf_counter()
+        if it:
+            t_mel.append(t1 - t0); t_enc.append(t2 - t1)
+    med = lambda v: sorted(v)[len(v) // 2]
+    m_mel, m_enc, m_all = med(t_mel), med(t_enc), med([x + y for x, y in zip(t_mel, t_enc)])
+    base = {"value": round(n / m_all, 3), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d of the step's clips, fp32, parity mode; 1 warm-up + 3 timed passes, median (mel %.2f s + encoder %.2f s per pass)" % (n, m_mel, m_enc),
+            "threads_note": "torch threads = min(cores available to this process = %d, cap AWT_CPU_THREADS = %d)" % (avail, cap),
+            "mel_clips_per_s": round(n / m_mel, 3), "encoder_clips_per_s": round(n / m_enc, 3)}
+    hid, feats = enc.encode_pcm(pcm[:n], return_features=True)
+    e = oenc.error_norms(hid.cpu().numpy(), ref.numpy())
+    parity = {"mel_max_abs": float(np.abs(feats.cpu().numpy() - mel).max()), "mel_tolerance": 1e-5,
+              "hidden_max_abs": e["max_abs"], "hidden_mean_abs": e["mean_abs"], "hidden_rel_l2": e["rel_l2"],
+              "hidden_tolerance": 1e-3, "norm_applied": "max_abs", "sample_clips": n}
+    return base, parity, ref
 
 
-def main():
-    a = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    dev = torch.device("cuda", local_rank if a.dist_backend == "nccl" else 0)
-    torch.cuda.set_device(dev)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if a.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group("gloo")
-
-    if a.workload == "finetune":
-        return finetune_main(a, rank, local_rank, world, dev)
-
+def encode_main(a):
+    R = Ranks(a)
+    torch, dev, rank, world = R.torch, R.dev, R.rank, R.world
     from mlx8_ws_audio_transformer_amd import _lib, synth, weights as wts
     from mlx8_ws_audio_transformer_amd.encoder import NativeWhisperEncoder
 
@@ -194,7 +398,7 @@ def main():
     _lib.prof_enable(True, ["gemm"])
     for k in _lib.PROF_CLASSES:
         _lib.prof_collect(k)
-    dt, out = timed_steps(enc, pcm, a.steps, world, dev)
+    dt, mine, out = R.timed(lambda: enc.encode_pcm(pcm), a.steps)
     prof = {"gemm": _lib.prof_collect("gemm")}
     # the other classes' time shares come from one extra, untimed step
     _lib.prof_enable(True, [k for k in _lib.PROF_CLASSES if k != "gemm"])
@@ -204,44 +408,45 @@ def main():
             ms, n, fl = _lib.prof_collect(k)
             prof[k] = (ms * a.steps, n, fl)      # scaled so the per-step division below applies to every class
     _lib.prof_enable(False)
+    rates = R.gather(B * a.steps / mine)
 
     clips = B * world * a.steps
     value = clips / dt
     gemm_ms, gemm_n, gemm_flop = prof["gemm"]
     achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-    terms = 3 if a.precision == "bf16x3" else 1
-    props = torch.cuda.get_device_properties(dev)
-    device_info = {"name": props.name, "arch": getattr(props, "gcnArchName", ""), "compute_units": props.multi_processor_count,
-                   "hbm_gib": round(props.total_memory / 2 ** 30, 1),
-                   "note": "peaks used: 2.5 PFLOP/s dense bf16 MFMA, 8 TB/s HBM3E (MI355X_MICROARCH.md); the encoder runs at the "
-                           "1400 W package limit with sclk 1.9-2.1 GHz (DESIGN.md 4.2)"}
+    terms = _lib.MFMA_PER_PAIR[a.precision]
     result = {
         "metric": "4s@16kHz clips/sec through mel+Whisper-%s encoder" % a.model,
         "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16", "data": "synthetic", "device": device_info,
+        "dtype": "bf16", "data": "synthetic", "device": device_info(torch, dev),
         "config": {"workload": "int16 PCM [B,64000] in HBM -> Whisper log-mel [B,80,%d] -> Whisper-%s encoder -> hidden [B,%d,%d] fp32"
                                % (cfg.n_frames, a.model, cfg.max_source_positions, cfg.d_model),
                    "mode": "trimmed (NOT reference-equivalent)" if a.trimmed else "parity (clip zero-padded to 30 s, as the reference computes)",
                    "clips_per_gpu_per_step": B, "precision": a.precision,
                    "mfma_products_per_fragment_pair": terms, "weights": "random-init Whisper-%s shape, seed 0" % a.model,
                    "parallelism": "dp%d (clip shards, no data-path collective)" % world},
-        "roofline": {"bound": "mfma", "kernel": "gemm_kernel<TERMS=%d> (all encoder GEMMs: conv stem, QKV, out, fc1, fc2)" % terms,
+        "roofline": {"bound": "mfma", "kernel": "gemm_kernel<%s> (all encoder GEMMs: conv stem, QKV, out, fc1, fc2)" % a.precision,
                      "achieved": round(achieved, 2), "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / PEAK_BF16_DENSE_TFLOPS, 4), "traffic": None,
                      "launches": gemm_n, "avg_launch_ms": round(gemm_ms / max(gemm_n, 1), 4),
                      "mfma_issue_frac": round(terms * achieved / PEAK_BF16_DENSE_TFLOPS, 4)},
         "time_share_ms_per_step": {k: round(v[0] / a.steps, 3) for k, v in prof.items()},
+        "ranks": R.describe(rates), "build": source_hash(),
     }
     # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (tools/profile_round.sh); the committed
-    # summary of the latest profiled build is attached when it matches this workload
-    tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    if os.path.exists(tpath) and a.model == "small" and not a.trimmed and a.precision == "bf16x3" and B == 64:
+    # summary is attached only when it was measured on THIS build (source hash) and this workload
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath) and a.model == "small" and not a.trimmed and B == 64:
         try:
             tj = json.load(open(tpath))
-            result["roofline"]["traffic"] = round(tj["per_kernel"]["gemm_kernel"]["hbm_bytes_per_launch"])
-            result["roofline"]["traffic_note"] = "bytes per GEMM launch, FETCH_SIZE x2 (gfx950) + WRITE_SIZE, from profiles/r01_traffic.json"
-            result["roofline"]["algorithmic_bytes_per_launch"] = round(GEMM_ALGO_BYTES_PER_STEP / 50)
+            if tj.get("build") == result["build"] and tj.get("precision") == a.precision:
+                result["roofline"]["traffic"] = round(tj["per_kernel"]["gemm_kernel"]["hbm_bytes_per_launch"])
+                result["roofline"]["traffic_note"] = "bytes per GEMM launch, FETCH_SIZE x2 (gfx950) + WRITE_SIZE, rocprofv3 --pmc passes on this build (profiles/traffic.json)"
+                result["roofline"]["algorithmic_bytes_per_launch"] = round(GEMM_ALGO_BYTES_PER_STEP / 50)
+            else:
+                result["roofline"]["traffic_note"] = "profiles/traffic.json was measured on build %s (%s), this is %s: not attached" % (
+                    tj.get("build"), tj.get("precision"), result["build"])
         except Exception:
             pass
     gf = ENCODER_GFLOP_PER_CLIP.get((a.model, a.trimmed))
@@ -252,47 +457,37 @@ def main():
     if rank == 0 and world == 1:
         # ---- package power and shader clock while the headline workload runs (rocm-smi in a child process, outside the timed
         #      region): the encoder sits at the package power limit, which is what caps roofline.frac
-        result["power"] = sample_power(lambda: enc.encode_pcm(pcm), dev)
-        # ---- single-pass bf16 mode, reported beside the headline (it does not meet the 1e-3 bound)
-        if not a.no_fast_mode and a.precision == "bf16x3":
-            fast = NativeWhisperEncoder(cfg, precision="bf16", device=str(dev), chunk_clips=a.chunk, seed=0, init_profile="hf").eval()
-            for _ in range(max(1, a.warmup)):
-                fast.encode_pcm(pcm)
-            fdt, fout = timed_steps(fast, pcm, a.steps, 1, dev)
-            d = (fout[: a.cpu_clips].double() - out[: a.cpu_clips].double())
-            result["fast_bf16_mode"] = {"value": round(B * a.steps / fdt, 2), "unit": "clips/s",
-                                        "ms_per_step": round(fdt / a.steps * 1e3, 3),
-                                        "vs_bf16x3_max_abs": float(d.abs().max()), "vs_bf16x3_rel_l2": float(d.norm() / out[: a.cpu_clips].double().norm()),
-                                        "note": "single bf16 MFMA product per fragment pair; misses the 1e-3 hidden-state bound"}
-            del fast
+        result["power"] = sample_power(torch, lambda: enc.encode_pcm(pcm), dev)
+        # ---- the other operand modes, reported beside the headline with all three error norms vs the headline's output
+        if not a.no_fast_mode:
+            side = {}
+            for prec in PRECISIONS:
+                if prec == a.precision:
+                    continue
+                other = NativeWhisperEncoder(cfg, precision=prec, device=str(dev), chunk_clips=a.chunk, seed=0, init_profile="hf").eval()
+                for _ in range(max(1, a.warmup)):
+                    other.encode_pcm(pcm)
+                fdt, _, fout = R.timed(lambda: other.encode_pcm(pcm), a.steps)
+                d = (fout[: a.cpu_clips].double() - out[: a.cpu_clips].double())
+                side[prec] = {"value": round(B * a.steps / fdt, 2), "unit": "clips/s", "ms_per_step": round(fdt / a.steps * 1e3, 3),
+                              "vs_headline_max_abs": float(d.abs().max()), "vs_headline_mean_abs": float(d.abs().mean()),
+                              "vs_headline_rel_l2": float(d.norm() / out[: a.cpu_clips].double().norm()),
+                              "mfma_products_per_fragment_pair": _lib.MFMA_PER_PAIR[prec]}
+                del other
+            result["other_precisions"] = side
         # ---- CPU baseline: the oracle (CPU restatement of the reference path) on this host's cores, bounded sample
         if not a.no_cpu_baseline:
-            from oracle import encoder as oenc, logmel as omel
-            n = min(a.cpu_clips, B)
-            # the GPU box gives one GPU's share of the host (16 cores); os.cpu_count() reports the whole machine
-            ncpu = min(len(os.sched_getaffinity(0)), int(os.environ.get("AWT_CPU_THREADS", "16")))
-            torch.set_num_threads(ncpu)
-            W = wts.init_encoder_weights(cfg, 0, "hf")
-            clips_f32 = [synth.pcm_i16_to_f32(c) for c in pcm_host[:n]]
-            t0 = time.perf_counter()
-            mel = omel.whisper_logmel(clips_f32, n_samples=cfg.n_frames * 160)
-            t1 = time.perf_counter()
-            with torch.no_grad():
-                ref = oenc.encoder_forward(W, mel, cfg.heads)
-            t2 = time.perf_counter()
-            result["cpu_baseline"] = {"value": round(n / (t2 - t0), 3), "unit": "clips/s", "cores": torch.get_num_threads(),
-                                      "kind": "port", "sample": "%d of the step's clips, fp32, 1 pass (mel %.2f s + encoder %.2f s)" % (n, t1 - t0, t2 - t1),
-                                      "mel_clips_per_s": round(n / (t1 - t0), 3), "encoder_clips_per_s": round(n / (t2 - t1), 3)}
-            hid, feats = enc.encode_pcm(pcm[:n], return_features=True)
-            e = oenc.error_norms(hid.cpu().numpy(), ref.numpy())
-            result["parity"] = {"mel_max_abs": float(np.abs(feats.cpu().numpy() - mel).max()), "mel_tolerance": 1e-5,
-                                "hidden_max_abs": e["max_abs"], "hidden_mean_abs": e["mean_abs"], "hidden_rel_l2": e["rel_l2"],
-                                "hidden_tolerance": 1e-3, "norm_applied": "max_abs", "sample_clips": n}
+            result["cpu_baseline"], result["parity"], _ = cpu_baseline_and_parity(a, torch, cfg, enc, pcm, pcm_host, out)
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
-        import torch.distributed as dist
-        dist.destroy_process_group()
+    R.finish()
+
+
+def main():
+    a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(spawn_ranks(a))                 # the parent never initialises the GPU
+    {"encode": encode_main, "sweep": sweep_main, "finetune": finetune_main, "noop": noop_main}[a.workload](a)
 
 
 if __name__ == "__main__":

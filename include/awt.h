@@ -151,6 +151,35 @@ int awt_encoder_forward_train(awt_encoder* e, const float* input_features, int B
                               void* saved, size_t saved_bytes, void* stream);
 int awt_encoder_backward(awt_encoder* e, const float* d_last_hidden_state, int B, void* saved, size_t saved_bytes,
                          float* lora_grads, size_t n_grads, void* stream);
+/* Same with flags.  AWT_BWD_ACCUMULATE: lora_grads += the gradients (gradient accumulation over micro-batches) instead
+ * of overwriting.  AWT_BWD_ALLREDUCE: after awt_encoder_set_comm, the gradients (after accumulation) are averaged over
+ * the communicator's ranks inside this call, layer group by layer group: the group holding the upper layers is
+ * all-reduced on the communicator's side stream while the lower layers' backward still runs on `stream`; `stream` waits
+ * for the last group before anything enqueued after this call reads lora_grads (one flat buffer, reduced
+ * in place, overlapped with the remaining backward). */
+enum { AWT_BWD_ACCUMULATE = 1, AWT_BWD_ALLREDUCE = 2 };
+int awt_encoder_backward_ex(awt_encoder* e, const float* d_last_hidden_state, int B, void* saved, size_t saved_bytes,
+                            float* lora_grads, size_t n_grads, uint32_t flags, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Data-parallel gradient exchange over RCCL / xGMI (build-defined: the reference has no distributed code, SURVEY.md
+ * §5 last row, §8a a17, §8e).  One process per GPU; rank 0 calls awt_comm_unique_id and hands the 128 bytes to the other
+ * ranks out of band (torch.distributed's store in finetune.py); every rank then calls awt_comm_create (collective).
+ * librccl.so is loaded on first use (dlopen), so the library itself loads on hosts without RCCL.
+ * awt_allreduce_{sum,mean}_f32: in-place ncclAllReduce (ncclSum / ncclAvg) of `n` floats at device pointer `buf`,
+ * enqueued on `stream`.  The fine-tune step's exchange is ONE flat buffer (r = 16 on q, v of Whisper-small: 589 824
+ * floats = 2.36 MB): latency-bound, so it is never split finer than awt_encoder_set_comm's layer groups. */
+typedef struct awt_comm awt_comm;
+enum { AWT_COMM_ID_BYTES = 128 };
+int awt_comm_unique_id(void* id_out /* host, AWT_COMM_ID_BYTES */);
+int awt_comm_create(awt_ctx* c, const void* id /* host, AWT_COMM_ID_BYTES */, int rank, int world, awt_comm** out);
+void awt_comm_destroy(awt_comm* m);
+int awt_comm_world(const awt_comm* m);
+int awt_allreduce_sum_f32(awt_comm* m, float* buf, size_t n, void* stream);
+int awt_allreduce_mean_f32(awt_comm* m, float* buf, size_t n, void* stream);
+/* Attach a communicator to an encoder for AWT_BWD_ALLREDUCE; `groups` >= 1 layer groups (2 = upper / lower half;
+ * clamped to the layer count).  m = NULL detaches. */
+int awt_encoder_set_comm(awt_encoder* e, awt_comm* m, int groups);
 
 /* PCM -> hidden states in one call (log-mel + encoder, chunked so intermediates stay cache-resident):
  * the batched form of `WhisperAudioEncoder.forward` (.charles/music2midi/model.py:42-123).

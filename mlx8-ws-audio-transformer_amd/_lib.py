@@ -31,6 +31,9 @@ class EncoderCfg(C.Structure):
                 ("lora_alpha", C.c_float), ("lora_targets", C.c_uint32), ("chunk_clips", C.c_int32), ("training", C.c_int32), ("backward_terms", C.c_int32)]
 
 
+MFMA_PER_PAIR = {"bf16": 1, "bf16x3": 3}   # MFMA-equivalents issued per fragment pair, by precision mode
+BWD_ACCUMULATE, BWD_ALLREDUCE = 1, 2
+COMM_ID_BYTES = 128
 LORA_BITS = {"q_proj": 1, "k_proj": 2, "v_proj": 4, "out_proj": 8, "fc1": 16, "fc2": 32}
 PROF_CLASSES = {"logmel": 0, "gemm": 1, "attention": 2, "layernorm": 3, "other": 4}
 
@@ -55,6 +58,14 @@ _SIGNATURES = {
     "awt_encoder_lora_grad_count": (_sz, [_vp]),
     "awt_encoder_forward_train": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "awt_encoder_backward": (_i, [_vp, _vp, _i, _vp, _sz, _vp, _sz, _vp]),
+    "awt_encoder_backward_ex": (_i, [_vp, _vp, _i, _vp, _sz, _vp, _sz, C.c_uint32, _vp]),
+    "awt_comm_unique_id": (_i, [_vp]),
+    "awt_comm_create": (_i, [_vp, _vp, _i, _i, C.POINTER(_vp)]),
+    "awt_comm_destroy": (None, [_vp]),
+    "awt_comm_world": (_i, [_vp]),
+    "awt_allreduce_sum_f32": (_i, [_vp, _vp, _sz, _vp]),
+    "awt_allreduce_mean_f32": (_i, [_vp, _vp, _sz, _vp]),
+    "awt_encoder_set_comm": (_i, [_vp, _vp, _i]),
     "awt_audio_encode_workspace_bytes": (_sz, [_vp, _i]),
     "awt_audio_encode": (_i, [_vp, _vp, _i, _i64, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "awt_op_linear": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),

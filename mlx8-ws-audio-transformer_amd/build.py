@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libawt.so")
-SOURCES = ["awt_api.hip", "logmel.hip", "gemm.hip", "attention.hip", "attention_bwd.hip", "elementwise.hip"]
+SOURCES = ["awt_api.hip", "logmel.hip", "gemm.hip", "attention.hip", "attention_bwd.hip", "elementwise.hip", "comm.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 
@@ -30,7 +30,7 @@ def _stale(target: str, deps) -> bool:
 
 def _compile(src: str, force: bool) -> str:
     obj = os.path.join(OBJ, src.replace(".hip", ".o"))
-    deps = [os.path.join(CSRC, src), os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "awt.h")]
+    deps = [os.path.join(CSRC, src), os.path.join(CSRC, "common.h"), os.path.join(CSRC, "comm.h"), os.path.join(HERE, "..", "include", "awt.h")]
     if force or _stale(obj, deps):
         cmd = [HIPCC, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -46,7 +46,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as ex:
         objs = list(ex.map(lambda s: _compile(s, force), SOURCES))
     if force or _stale(LIB, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-ldl"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")

@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "common.h"
+#include "comm.h"
 
 // ------------------------------------------------------------------------------------------------ errors
 static thread_local std::string g_err;
@@ -176,6 +177,8 @@ struct awt_encoder {
   std::vector<void*> allocs;
   std::vector<std::string> seen;   // names uploaded so far
   int chunk = 16;
+  awt_comm* comm = nullptr;        // AWT_BWD_ALLREDUCE: adapter gradients are averaged over this communicator's ranks
+  int comm_groups = 2;
 };
 
 namespace {
@@ -691,9 +694,27 @@ extern "C" int awt_encoder_forward_train(awt_encoder* e, const float* mel, int B
   return launch_layernorm(e->ctx, w.x_final, e->lnf_g, e->lnf_b, B * e->cfg.n_ctx, e->cfg.d_model, 1e-5f, hidden, nullptr, nullptr, s);
 }
 
+extern "C" int awt_encoder_set_comm(awt_encoder* e, awt_comm* m, int groups) {
+  AWT_REQUIRE(e, AWT_ERR_INVALID, "encoder_set_comm: null encoder");
+  AWT_REQUIRE(groups >= 1, AWT_ERR_INVALID, "encoder_set_comm: groups must be >= 1");
+  AWT_REQUIRE(!m || m->ctx == e->ctx, AWT_ERR_INVALID, "encoder_set_comm: communicator and encoder belong to different contexts");
+  e->comm = m;
+  e->comm_groups = std::min(std::min(groups, 4), e->cfg.n_layers);
+  return AWT_OK;
+}
+
 extern "C" int awt_encoder_backward(awt_encoder* e, const float* d_hidden, int B, void* saved, size_t saved_bytes, float* lora_grads,
                                     size_t n_grads, void* stream) {
+  return awt_encoder_backward_ex(e, d_hidden, B, saved, saved_bytes, lora_grads, n_grads, 0u, stream);
+}
+
+extern "C" int awt_encoder_backward_ex(awt_encoder* e, const float* d_hidden, int B, void* saved, size_t saved_bytes, float* lora_grads,
+                                       size_t n_grads, uint32_t flags, void* stream) {
   AWT_REQUIRE(e && d_hidden && saved && lora_grads && B > 0, AWT_ERR_INVALID, "encoder_backward: bad argument");
+  AWT_REQUIRE(!(flags & ~(uint32_t)(AWT_BWD_ACCUMULATE | AWT_BWD_ALLREDUCE)), AWT_ERR_INVALID, "encoder_backward: unknown flag");
+  AWT_REQUIRE(!(flags & AWT_BWD_ALLREDUCE) || e->comm, AWT_ERR_STATE, "encoder_backward: AWT_BWD_ALLREDUCE needs awt_encoder_set_comm first");
+  const int accumulate = (flags & AWT_BWD_ACCUMULATE) ? 1 : 0;
+  const bool exchange = (flags & AWT_BWD_ALLREDUCE) != 0;
   AWT_REQUIRE(e->cfg.training, AWT_ERR_STATE, "encoder_backward: encoder was not created with cfg.training");
   AWT_REQUIRE(saved_bytes >= awt_encoder_train_workspace_bytes(e, B), AWT_ERR_WORKSPACE, "encoder_backward: saved buffer too small");
   AWT_REQUIRE(n_grads == awt_encoder_lora_grad_count(e), AWT_ERR_INVALID, "encoder_backward: lora_grads has the wrong element count");
@@ -754,12 +775,24 @@ extern "C" int awt_encoder_backward(awt_encoder* e, const float* d_hidden, int B
       float* dA = g + (size_t)slot_out * 2 * r * d;
       float* dB = dA + (size_t)r * d;
       rc = launch_outer_reduce(e->ctx, w.du[0], w.du[1], L.lq.kp, which * r, r, b.ln1[0], b.ln1[1], d, 0, d, M, lscale, dA, d, 1,
-                               w.partial, w.partial_bytes, s);
+                               w.partial, w.partial_bytes, accumulate, s);
       if (rc) return rc;
       rc = launch_outer_reduce(e->ctx, b.u[0], b.u[1], L.lq.kp, which * r, r, w.dqkv[0], w.dqkv[1], 3 * d, which * d, d, M, 1.0f, dB, 1, r,
-                               w.partial, w.partial_bytes, s);
+                               w.partial, w.partial_bytes, accumulate, s);
       if (rc) return rc;
       ++slot_out;
+    }
+    // ---- gradient exchange: layers [li, group_hi) are final -- average them over the ranks on the side stream while the
+    //      lower layers' backward continues on `s`
+    if (exchange) {
+      const int G = e->comm_groups, Lr = c.n_layers;
+      const int grp = (int)((int64_t)li * G / Lr);                       // layer li belongs to group grp (0 = lowest layers)
+      const int lo_layer = (int)(((int64_t)grp * Lr + G - 1) / G);       // first layer of that group
+      if (li == lo_layer) {
+        const int hi_layer = (int)(((int64_t)(grp + 1) * Lr + G - 1) / G);
+        rc = comm_reduce_async(e->comm, lora_grads + (size_t)li * per_layer, (size_t)(hi_layer - li) * per_layer, s);
+        if (rc) return rc;
+      }
     }
     if (li == 0) break;   // nothing below the first adapter needs a gradient
     // ---- dln = [dqkv | du] [Wqkv | lscale A]  ; dx_in = dx_mid + LN1_bwd(dln)
@@ -773,5 +806,6 @@ extern "C" int awt_encoder_backward(awt_encoder* e, const float* d_hidden, int B
     rc = launch_layernorm_bwd(e->ctx, w.dln, b.x_in, L.ln1_g, dx, M, d, 1e-5f, dx_other, w.dxp[0], w.dxp[1], s); if (rc) return rc;
     std::swap(dx, dx_other);
   }
+  if (exchange) { rc = comm_join(e->comm, s); if (rc) return rc; }
   return AWT_OK;
 }

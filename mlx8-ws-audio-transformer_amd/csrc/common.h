@@ -182,8 +182,8 @@ int launch_layernorm_bwd(awt_ctx* c, const float* dy, const float* x, const floa
 // dst(row_off + c, col_off + n) = scale * src[n, c]   (transposed copy of an [N, C] fp32 matrix into fragment-major planes)
 int launch_pack_weight_t(awt_ctx* c, const float* src, int N, int C, int64_t ld, int row_off, int col_off, float scale, bf16_t* hi,
                          bf16_t* lo, hipStream_t s);
-// out[j * sj + n * sn] = scale * sum_m X[m, xcol + j] * Y[m, ycol + n]   for j < r, n < ny  (LoRA dA / dB; fp32 result)
+// out[j * sj + n * sn] (+)= scale * sum_m X[m, xcol + j] * Y[m, ycol + n]   for j < r, n < ny  (LoRA dA / dB; fp32 result)
 int launch_outer_reduce(awt_ctx* c, const bf16_t* x_hi, const bf16_t* x_lo, int64_t ldx, int xcol, int r, const bf16_t* y_hi,
                         const bf16_t* y_lo, int64_t ldy, int ycol, int ny, int M, float scale, float* out, int64_t sj, int64_t sn,
-                        float* partial, size_t partial_bytes, hipStream_t s);
+                        float* partial, size_t partial_bytes, int accumulate, hipStream_t s);
 size_t outer_reduce_partial_bytes(int M, int r, int ny);

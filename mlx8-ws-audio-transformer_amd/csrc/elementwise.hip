@@ -286,13 +286,14 @@ __global__ __launch_bounds__(256) void outer_reduce_kernel(const bf16_t* x_hi, c
 }
 
 __global__ __launch_bounds__(256) void outer_reduce_final_kernel(const float* partial, int nslab, int R, int r, int ny, float scale,
-                                                                 float* out, int64_t sj, int64_t sn) {
+                                                                 float* out, int64_t sj, int64_t sn, int accumulate) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= r * ny) return;
   const int j = idx / ny, n = idx - j * ny;
   float acc = 0.f;
   for (int s = 0; s < nslab; ++s) acc += partial[((int64_t)s * R + j) * ny + n];
-  out[j * sj + n * sn] = acc * scale;
+  float* o = out + j * sj + n * sn;
+  *o = accumulate ? *o + acc * scale : acc * scale;     // accumulate: gradient accumulation over micro-batches
 }
 
 }  // namespace
@@ -363,7 +364,7 @@ size_t outer_reduce_partial_bytes(int M, int r, int ny) {
 
 static int launch_outer_reduce_1(awt_ctx* c, const bf16_t* x_hi, const bf16_t* x_lo, int64_t ldx, int xcol, int r, const bf16_t* y_hi,
                         const bf16_t* y_lo, int64_t ldy, int ycol, int ny, int M, float scale, float* out, int64_t sj, int64_t sn,
-                        float* partial, size_t partial_bytes, hipStream_t s) {
+                        float* partial, size_t partial_bytes, int accumulate, hipStream_t s) {
   AWT_REQUIRE(x_hi && y_hi && out && partial && r > 0 && r <= 32 && ny > 0 && ny % 4 == 0 && ny <= 1024, AWT_ERR_INVALID, "outer_reduce: bad shape");
   AWT_REQUIRE(ldy % 4 == 0 && ycol % 4 == 0, AWT_ERR_INVALID, "outer_reduce: Y columns must be 8-byte aligned");
   AWT_REQUIRE(partial_bytes >= outer_reduce_partial_bytes(M, r, ny), AWT_ERR_WORKSPACE, "outer_reduce: partial buffer too small");
@@ -377,7 +378,7 @@ static int launch_outer_reduce_1(awt_ctx* c, const bf16_t* x_hi, const bf16_t* x
   else if (R == 16) hipLaunchKernelGGL(outer_reduce_kernel<16>, dim3(nslab), dim3(256), 0, s, x_hi, x_lo, ldx, xcol, y_hi, y_lo, ldy, ycol, ny, M, partial);
   else hipLaunchKernelGGL(outer_reduce_kernel<32>, dim3(nslab), dim3(256), 0, s, x_hi, x_lo, ldx, xcol, y_hi, y_lo, ldy, ycol, ny, M, partial);
   AWT_HIP_CHECK(hipGetLastError());
-  hipLaunchKernelGGL(outer_reduce_final_kernel, dim3((r * ny + 255) / 256), dim3(256), 0, s, partial, nslab, R, r, ny, scale, out, sj, sn);
+  hipLaunchKernelGGL(outer_reduce_final_kernel, dim3((r * ny + 255) / 256), dim3(256), 0, s, partial, nslab, R, r, ny, scale, out, sj, sn, accumulate);
   AWT_HIP_CHECK(hipGetLastError());
   return AWT_OK;
 }
@@ -385,11 +386,11 @@ static int launch_outer_reduce_1(awt_ctx* c, const bf16_t* x_hi, const bf16_t* x
 // Y blocks wider than the kernel's 1024 columns (256 threads x 4) are reduced in column chunks (Whisper large: d = 1280)
 int launch_outer_reduce(awt_ctx* c, const bf16_t* x_hi, const bf16_t* x_lo, int64_t ldx, int xcol, int r, const bf16_t* y_hi,
                         const bf16_t* y_lo, int64_t ldy, int ycol, int ny, int M, float scale, float* out, int64_t sj, int64_t sn,
-                        float* partial, size_t partial_bytes, hipStream_t s) {
+                        float* partial, size_t partial_bytes, int accumulate, hipStream_t s) {
   for (int n0 = 0; n0 < ny; n0 += 1024) {
     const int nc = ny - n0 < 1024 ? ny - n0 : 1024;
     int rc = launch_outer_reduce_1(c, x_hi, x_lo, ldx, xcol, r, y_hi, y_lo, ldy, ycol + n0, nc, M, scale, out + (int64_t)n0 * sn, sj, sn,
-                                   partial, partial_bytes, s);
+                                   partial, partial_bytes, accumulate, s);
     if (rc) return rc;
   }
   return AWT_OK;

@@ -62,6 +62,22 @@ class _EncoderLoRAFunction(torch.autograd.Function):
         enc, L = ctx.enc, _lib.lib()
         d_out = d_out.to(torch.float32).contiguous()
         n = L.awt_encoder_lora_grad_count(enc._handle)
+        if enc._grad_flat is not None:
+            # bound gradient buffer (bind_grad_buffer): the library writes / accumulates the adapter gradients straight into
+            # the flat buffer the parameters' .grad tensors are views of, and -- when asked -- averages them over the ranks
+            # inside the same call; autograd gets no tensors for them
+            flags = 0 if (enc._grad_fresh or enc._grad_params[0].grad is None) else _lib.BWD_ACCUMULATE
+            if enc.grad_sync and enc._comm is not None:
+                flags |= _lib.BWD_ALLREDUCE
+            with torch.cuda.device(d_out.device):
+                _lib.check(L.awt_encoder_backward_ex(enc._handle, _lib.ptr(d_out), ctx.B, _lib.ptr(ctx.saved), ctx.saved.numel(),
+                                                     _lib.ptr(enc._grad_flat), n, flags, _lib.stream_handle()))
+            ctx.saved = None
+            enc._grad_fresh = False
+            for p, v in zip(enc._grad_params, enc._grad_views):
+                if p.grad is not v:
+                    p.grad = v
+            return (None, None, *([None] * len(ctx.shapes)))
         flat = torch.empty(n, dtype=torch.float32, device=d_out.device)
         with torch.cuda.device(d_out.device):
             _lib.check(L.awt_encoder_backward(enc._handle, _lib.ptr(d_out), ctx.B, _lib.ptr(ctx.saved), ctx.saved.numel(), _lib.ptr(flat), n,
@@ -124,6 +140,13 @@ class NativeWhisperEncoder(nn.Module):
         self._chunk = chunk_clips
         self._synced: Dict[str, int] = {}
         self._ws: Optional[torch.Tensor] = None
+        # bound gradient buffer (bind_grad_buffer) and the communicator its exchange runs on (set_comm)
+        self._grad_flat: Optional[torch.Tensor] = None
+        self._grad_params: list = []
+        self._grad_views: list = []
+        self._grad_fresh = True
+        self._comm = None
+        self.grad_sync = True       # False: this backward only accumulates (all but the last micro-batch of a step)
 
     # ------------------------------------------------------------------------------------------------ plumbing
     @property
@@ -173,6 +196,55 @@ class NativeWhisperEncoder(nn.Module):
                 n += 1
         return n
 
+    # ------------------------------------------------------------------------------------------------ gradients
+    def lora_parameters_library_order(self) -> list:
+        """Adapter parameters in the order awt_encoder_backward lays their gradients out: per layer, per target in
+        (q_proj, k_proj, v_proj) order: lora_A then lora_B (include/awt.h)."""
+        order = [t for t in ("q_proj", "k_proj", "v_proj") if self.lora is not None and t in self.lora.targets]
+        params = []
+        for i in range(self.cfg.layers):
+            for t in order:
+                leaf = getattr(getattr(getattr(self.layers, str(i)), "self_attn"), t)
+                params += [leaf.lora_A, leaf.lora_B]
+        return params
+
+    def lora_grad_count(self) -> int:
+        self._ensure_handle()
+        return int(_lib.lib().awt_encoder_lora_grad_count(self._handle))
+
+    def bind_grad_buffer(self, flat: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Bind the adapter gradients to ONE flat fp32 device buffer (library order): every adapter parameter's `.grad`
+        becomes a view of it, the native backward writes there directly (accumulating from the second backward on, until
+        `zero_adapter_grads()`), and the data-parallel exchange reduces it in place (dist.FlatGradBucket / set_comm)."""
+        if not self.trainable:
+            raise ValueError("bind_grad_buffer needs trainable=True")
+        n = self.lora_grad_count()
+        if flat is None:
+            flat = torch.zeros(n, dtype=torch.float32, device=self.device)
+        if flat.numel() != n or flat.dtype != torch.float32 or not flat.is_contiguous() or flat.device != self.device:
+            raise ValueError(f"flat must be a contiguous float32 tensor of {n} elements on {self.device}")
+        self._grad_flat = flat
+        self._grad_params = self.lora_parameters_library_order()
+        self._grad_views, off = [], 0
+        for p in self._grad_params:
+            k = p.numel()
+            self._grad_views.append(flat[off: off + k].view_as(p))
+            p.grad = self._grad_views[-1]
+            off += k
+        self._grad_fresh = True
+        return flat
+
+    def zero_adapter_grads(self) -> None:
+        """With a bound buffer: the next backward overwrites instead of accumulating (no kernel is launched)."""
+        self._grad_fresh = True
+
+    def set_comm(self, comm, groups: int = 2) -> None:
+        """Average the adapter gradients over `comm`'s ranks (dist.AwtComm) inside the backward call, in `groups` layer
+        groups on the communicator's side stream (include/awt.h: awt_encoder_set_comm, AWT_BWD_ALLREDUCE)."""
+        self._ensure_handle()
+        _lib.check(_lib.lib().awt_encoder_set_comm(self._handle, None if comm is None else comm.handle, groups))
+        self._comm = comm
+
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
         res = super().load_state_dict(state_dict, strict=strict, **kw)
         self._synced.clear()
@@ -199,13 +271,7 @@ class NativeWhisperEncoder(nn.Module):
         self.sync_weights()
         L = _lib.lib()
         if self.trainable and torch.is_grad_enabled():
-            # library order of the adapter gradients: per layer, per target in (q, k, v) order: A then B
-            order = [t for t in ("q_proj", "k_proj", "v_proj") if t in self.lora.targets]
-            params = []
-            for i in range(self.cfg.layers):
-                for t in order:
-                    leaf = getattr(getattr(getattr(self.layers, str(i)), "self_attn"), t)
-                    params += [leaf.lora_A, leaf.lora_B]
+            params = self.lora_parameters_library_order()
             return BaseModelOutput(last_hidden_state=_EncoderLoRAFunction.apply(self, x, *params))
         ws = self._workspace(L.awt_encoder_workspace_bytes(self._handle, B))
         out = torch.empty((B, self.cfg.max_source_positions, self.cfg.d_model), dtype=torch.float32, device=self.device)

@@ -35,7 +35,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .dist import FlatGradBucket
+from .dist import AwtComm, FlatGradBucket, world_size
 from .encoder import NativeWhisperEncoder
 from .weights import EncoderConfig, LoraSpec, unit_variates
 
@@ -290,26 +290,68 @@ class Seq2SeqTrainer:
         self.optimizer = torch.optim.AdamW(params, lr=args.learning_rate, betas=(args.adam_beta1, args.adam_beta2),
                                            eps=args.adam_epsilon, weight_decay=args.weight_decay)
         self.scheduler = torch.optim.lr_scheduler.LambdaLR(self.optimizer, lambda s: linear_schedule(s, args.warmup_steps, args.max_steps))
-        self.bucket = FlatGradBucket(params)
+        # ONE flat gradient buffer: [ native encoder's adapters (library order; written by awt_encoder_backward_ex) | any
+        # other trainable parameter ]; every .grad is a view of it, the exchange and the clipping run on it in place
+        enc = getattr(model, "encoder", None)
+        self.native = enc if hasattr(enc, "bind_grad_buffer") and getattr(enc, "trainable", False) else None
+        if self.native is not None:
+            first = self.native.lora_parameters_library_order()
+            ids = {id(p) for p in first}
+            rest = [p for p in params if id(p) not in ids]
+            self.n_native = sum(p.numel() for p in first)
+            flat = torch.zeros(self.n_native + sum(p.numel() for p in rest), dtype=torch.float32, device=self.native.device)
+            self.native.bind_grad_buffer(flat[: self.n_native])
+            self.bucket = FlatGradBucket(first + rest, flat=flat)
+        else:
+            self.n_native = 0
+            self.bucket = FlatGradBucket(params)
+        self.comm: Optional[AwtComm] = None          # libawt's RCCL communicator (GPU + "nccl" process group, or forced)
+        self.exchange = "none"
+        self._setup_exchange()
         self.log_history: List[Dict[str, float]] = []
         self.global_step = 0
 
+    def _setup_exchange(self, force_native: bool = False) -> None:
+        """Choose how the flat gradient buffer is averaged over the ranks: libawt's RCCL communicator, issued from inside the
+        native backward on a side stream (GPU, "nccl" process group), or torch.distributed's all_reduce (gloo: CPU tests and
+        single-GPU rehearsals).  `force_native` builds a communicator even for one rank (exercises the RCCL path on one GPU)."""
+        import torch.distributed as dist
+        world = world_size()
+        backend = dist.get_backend() if world > 1 else None
+        if self.native is not None and (force_native or (world > 1 and backend == "nccl")):
+            self.comm = AwtComm(self.native.device)
+            self.native.set_comm(self.comm, groups=2)
+            self.exchange = "rccl (libawt awt_comm, in-backward, side stream, 2 layer groups)"
+        elif world > 1:
+            self.exchange = "torch.distributed all_reduce (%s) on the flat buffer" % backend
+
     def training_step(self, batch) -> float:
         """One optimizer step: forward + backward over `gradient_accumulation_steps` micro-batches (a single dict, or a list
-        of that many dicts), ONE all-reduce of the flat adapter-gradient buffer, clipping, AdamW, schedule."""
+        of that many dicts), ONE in-place mean all-reduce of the flat adapter-gradient buffer (inside the last native
+        backward when libawt's communicator is attached), clipping on the flat buffer, AdamW, schedule."""
         dev = self.model.encoder.device
         micro = batch if isinstance(batch, (list, tuple)) else [batch]
         total = 0.0
-        for mb in micro:
+        if self.native is not None:
+            self.native.zero_adapter_grads()                # the first backward overwrites the bound buffer: no zero-fill kernel
+            if self.bucket.numel > self.n_native:
+                self.bucket.flat[self.n_native:].zero_()
+        else:
+            self.bucket.zero()
+        for i, mb in enumerate(micro):
+            if self.native is not None:
+                self.native.grad_sync = i == len(micro) - 1   # exchange inside the last micro-batch's backward only
             out = self.model(input_features=mb["input_features"].to(dev), labels=mb["labels"].to(dev))
             (out.loss / len(micro)).backward()              # adapter .grad accumulates across micro-batches
             total += float(out.loss.detach())
-        self.bucket.allreduce_mean()
+        if self.comm is not None:
+            self.bucket.allreduce_mean(comm=self.comm, segment=slice(self.n_native, None))   # the native segment is already averaged
+        else:
+            self.bucket.allreduce_mean()
         if self.args.max_grad_norm and self.args.max_grad_norm > 0:
-            torch.nn.utils.clip_grad_norm_(self.bucket.params, self.args.max_grad_norm)
+            self.bucket.clip_norm_(self.args.max_grad_norm)
         self.optimizer.step()
         self.scheduler.step()
-        self.optimizer.zero_grad(set_to_none=True)
         self.global_step += 1
         return total / len(micro)
 

@@ -85,6 +85,29 @@ def synth_clips_i16(count: int, seed: int = 1234, first: int = 0, n_samples: int
     return pcm
 
 
+def _synth_span(args) -> np.ndarray:
+    count, seed, first, n_samples = args
+    return synth_clips_i16(count, seed, first, n_samples)
+
+
+def synth_clips_i16_parallel(count: int, seed: int = 1234, first: int = 0, n_samples: int = CLIP_SAMPLES, workers: int = 0) -> np.ndarray:
+    """`synth_clips_i16` over a pool of forked host processes (2.5 ms per clip on one core: the 10 000-clip sweep set
+    would take 25 s serially).  Call it BEFORE the process touches the GPU: the pool forks.  workers = 0: one per
+    available core, at most 16."""
+    import multiprocessing as mp
+    import os
+
+    if workers <= 0:
+        workers = min(16, len(os.sched_getaffinity(0)))
+    if count < 256 or workers == 1:
+        return synth_clips_i16(count, seed, first, n_samples)
+    per = -(-count // (4 * workers))
+    spans = [(min(per, count - lo), seed, first + lo, n_samples) for lo in range(0, count, per)]
+    with mp.get_context("fork").Pool(workers) as pool:
+        parts = pool.map(_synth_span, spans)
+    return np.concatenate(parts, axis=0)
+
+
 def pcm_i16_to_f32(pcm: np.ndarray) -> np.ndarray:
     """The decode convention of the reference's loaders (soundfile / torchaudio.load): int16 / 32768."""
     return pcm.astype(np.float32) / np.float32(32768.0)

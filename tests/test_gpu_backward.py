@@ -21,7 +21,10 @@ def _oracle_grads(W, LW, mel, cfg, spec, dout):
 
 
 @pytest.mark.parametrize("name,trimmed,targets,r", [("mini", True, ("q_proj", "v_proj"), 8), ("tiny", True, ("q_proj", "k_proj", "v_proj"), 16),
-                                                    ("mini", False, ("q_proj", "v_proj"), 8)])
+                                                    ("mini", False, ("q_proj", "v_proj"), 8),
+                                                    # BASELINE.json configs[2] / [3] at full size: Whisper-small (d = 768, 12 layers), parity
+                                                    # mode S = 1500, adapters on q_proj, v_proj, r = 8 and r = 16 (oracle autograd: ~20 s of CPU)
+                                                    ("small", False, ("q_proj", "v_proj"), 8), ("small", False, ("q_proj", "v_proj"), 16)])
 def test_lora_gradients_match_oracle_autograd(name, trimmed, targets, r):
     from mlx8_ws_audio_transformer_amd.encoder import NativeWhisperEncoder
     cfg = wts.config(name, trimmed)

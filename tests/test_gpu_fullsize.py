@@ -60,3 +60,67 @@ def test_sampled_clips_match_oracle(full):
     np.testing.assert_allclose(feats[idx].cpu().numpy(), mel, rtol=0, atol=1e-5)
     ref = oracle_enc.encoder_forward(wts.init_encoder_weights(cfg, 0, "hf"), mel, cfg.heads).numpy()
     assert np.abs(hidden[idx].cpu().numpy() - ref).max() < 1e-3
+
+
+# ---------------------------------------------------------------- BASELINE.json configs[2]: LoRA r = 8 fine-tune step, B = 64
+@pytest.fixture(scope="module")
+def step64():
+    from mlx8_ws_audio_transformer_amd.feature_extraction import logmel_whisper_device
+    from mlx8_ws_audio_transformer_amd.finetune import WhisperLoRAModel
+    cfg = wts.config("small")
+    pcm = torch.from_numpy(synth.synth_clips_i16(64, seed=1234, first=200)).cuda()
+    feats = logmel_whisper_device(pcm, n_frames=cfg.n_frames)
+    g = torch.Generator().manual_seed(0)
+    labels = torch.randint(0, 51864, (64, 12), generator=g); labels[:, 0] = 50258
+
+    def make():
+        model = WhisperLoRAModel(cfg, wts.LoraSpec(r=8, alpha=16.0), seed=0)
+        with torch.no_grad():
+            for p in model.lora_parameters():      # non-zero B so that both adapter matrices receive gradient
+                if p.shape[1] == 8:
+                    p.copy_(torch.from_numpy((0.02 * wts.unit_variates("b64", p.numel(), 1)).reshape(p.shape).astype(np.float32)))
+        return model
+    return cfg, feats, labels.cuda(), make
+
+
+def test_b64_encoder_backward_is_bit_reproducible_and_batch_mean_decomposes(step64):
+    cfg, feats, labels, make = step64
+    model = make()
+
+    def grads(sl):
+        model.zero_grad()
+        model(input_features=feats[sl], labels=labels[sl]).loss.backward()
+        return torch.cat([p.grad.flatten() for p in model.encoder.lora_parameters_library_order()]).clone()
+
+    g_full = grads(slice(0, 64))
+    assert torch.isfinite(g_full).all() and float(g_full.abs().max()) > 0
+    # every row carries 12 label tokens, so the batch-mean loss is the mean of the two half-batch means
+    g_half = (grads(slice(0, 32)) + grads(slice(32, 64))) / 2
+    assert float((g_full - g_half).abs().max()) < 1e-3 * float(g_full.abs().max())
+    # the native backward has no atomics: a fixed upstream gradient gives bit-identical adapter gradients at B = 64
+    dout = torch.from_numpy((wts.unit_variates("dout64", 64 * 1500 * 768, 7) / 40.0).astype(np.float32)).cuda().view(64, 1500, 768)
+    runs = []
+    for _ in range(2):
+        model.zero_grad()
+        model.encoder(feats).last_hidden_state.backward(dout)
+        runs.append(torch.cat([p.grad.flatten() for p in model.encoder.lora_parameters_library_order()]).clone())
+    assert torch.equal(runs[0], runs[1])
+
+
+def test_b64_training_steps_reduce_the_loss(step64):
+    from mlx8_ws_audio_transformer_amd.finetune import Seq2SeqTrainer, Seq2SeqTrainingArguments
+    cfg, feats, labels, make = step64
+    model = make()
+    args = Seq2SeqTrainingArguments(per_device_train_batch_size=64, learning_rate=1e-3, warmup_steps=0, max_steps=10, predict_with_generate=False)
+    tr = Seq2SeqTrainer(args=args, model=model)
+    assert tr.bucket.numel == 12 * 2 * 2 * 8 * 768                  # r = 8 on q_proj, v_proj of 12 layers: A and B
+    flat_ptr = tr.bucket.flat.data_ptr()
+    before = torch.cat([p.detach().flatten().clone() for p in model.lora_parameters()])
+    losses = [tr.training_step({"input_features": feats, "labels": labels}) for _ in range(3)]
+    assert all(np.isfinite(l) for l in losses)
+    assert losses[1] < losses[0] and losses[2] < losses[1], losses
+    after = torch.cat([p.detach().flatten() for p in model.lora_parameters()])
+    assert float((after - before).abs().max()) > 0
+    # the gradients never left the flat buffer: every adapter .grad is still a view of it
+    assert tr.bucket.flat.data_ptr() == flat_ptr and tr.bucket.bind(keep=True) == 0
+    assert model.encoder.lora_parameters_library_order()[0].grad.data_ptr() == flat_ptr
