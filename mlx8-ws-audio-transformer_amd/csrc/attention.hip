@@ -73,7 +73,7 @@ __device__ __forceinline__ bf16x4 tr_read(const char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)p);
 }
 
-template <int TERMS, int QT>
+template <int TERMS, int QT, bool F16>
 __global__ __launch_bounds__(kThreads, 2) void attention_kernel(AttnArgs a) {
   constexpr int QW = 32 * QT;       // queries per wave
   constexpr int QB = 4 * QW;        // queries per workgroup
@@ -170,11 +170,11 @@ __global__ __launch_bounds__(kThreads, 2) void attention_kernel(AttnArgs a) {
           if (TERMS == 3) asm volatile("" ::"v"(kl), "v"(qlo[t][ks]));
 #else
           if (TERMS == 3) {
-            sacc[t][kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qlo[t][ks], sacc[t][kt2], 0, 0, 0);
-            sacc[t][kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh[t][ks], sacc[t][kt2], 0, 0, 0);
+            sacc[t][kt2] = mfma32<F16>(kh, qlo[t][ks], sacc[t][kt2]);
+            sacc[t][kt2] = mfma32<F16>(kl, qh[t][ks], sacc[t][kt2]);
           }
 #endif
-          sacc[t][kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[t][ks], sacc[t][kt2], 0, 0, 0);
+          sacc[t][kt2] = mfma32<F16>(kh, qh[t][ks], sacc[t][kt2]);
         }
       }
     }
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(kThreads, 2) void attention_kernel(AttnArgs a) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             bf16_t hi, lo;
-            split_bf16(sacc[t][kt2][8 * s2 + j], hi, lo);
+            split16<F16>(sacc[t][kt2][8 * s2 + j], hi, lo);
             ph[t][j] = (short)hi;
             if (TERMS == 3) pl[t][j] = (short)lo;
           }
@@ -253,11 +253,11 @@ __global__ __launch_bounds__(kThreads, 2) void attention_kernel(AttnArgs a) {
             if (TERMS == 3) asm volatile("" ::"v"(vl), "v"(pl[t]));
 #else
             if (TERMS == 3) {
-              oacc[t][et] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl[t], oacc[t][et], 0, 0, 0);
-              oacc[t][et] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph[t], oacc[t][et], 0, 0, 0);
+              oacc[t][et] = mfma32<F16>(vh, pl[t], oacc[t][et]);
+              oacc[t][et] = mfma32<F16>(vl, ph[t], oacc[t][et]);
             }
 #endif
-            oacc[t][et] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph[t], oacc[t][et], 0, 0, 0);
+            oacc[t][et] = mfma32<F16>(vh, ph[t], oacc[t][et]);
           }
         }
       }
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(kThreads, 2) void attention_kernel(AttnArgs a) {
           } else {
             bf16_t hi[4], lo[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) split_bf16(v[j], hi[j], lo[j]);
+            for (int j = 0; j < 4; ++j) split16<F16>(v[j], hi[j], lo[j]);
             *reinterpret_cast<uint2*>(a.o_hi + row + e) = make_uint2(pack2(hi[0], hi[1]), pack2(hi[2], hi[3]));
             if (a.o_lo) *reinterpret_cast<uint2*>(a.o_lo + row + e) = make_uint2(pack2(lo[0], lo[1]), pack2(lo[2], lo[3]));
           }
@@ -299,13 +299,13 @@ __global__ __launch_bounds__(kThreads, 2) void attention_kernel(AttnArgs a) {
   }
 }
 
-template <int TERMS, int QT>
+template <int TERMS, int QT, bool F16 = false>
 int launch_t(const AttnArgs& a, hipStream_t s) {
   constexpr int lds = 2 * (TERMS == 3 ? 4 : 2) * PLANE;
   constexpr int QB = 4 * 32 * QT;
-  AWT_ONCE_PER_DEVICE(AWT_HIP_CHECK(hipFuncSetAttribute((const void*)attention_kernel<TERMS, QT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)));
+  AWT_ONCE_PER_DEVICE(AWT_HIP_CHECK(hipFuncSetAttribute((const void*)attention_kernel<TERMS, QT, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)));
   dim3 grid(((a.S + QB - 1) / QB) * a.B * a.H);
-  hipLaunchKernelGGL((attention_kernel<TERMS, QT>), grid, dim3(kThreads), lds, s, a);
+  hipLaunchKernelGGL((attention_kernel<TERMS, QT, F16>), grid, dim3(kThreads), lds, s, a);
   AWT_HIP_CHECK(hipGetLastError());
   return AWT_OK;
 }
@@ -314,9 +314,10 @@ int launch_t(const AttnArgs& a, hipStream_t s) {
 
 int launch_attention(awt_ctx* c, const bf16_t* q_hi, const bf16_t* q_lo, const bf16_t* k_hi, const bf16_t* k_lo,
                      const bf16_t* v_hi, const bf16_t* v_lo, bf16_t* o_hi, bf16_t* o_lo, float* o_f32, float* lse, int B, int H,
-                     int S, int terms, hipStream_t s) {
+                     int S, int prec, hipStream_t s) {
   AWT_REQUIRE(B > 0 && H > 0 && S > 0, AWT_ERR_INVALID, "attention: bad shape");
-  AWT_REQUIRE(terms == 1 || terms == 3, AWT_ERR_INVALID, "attention: terms must be 1 or 3");
+  AWT_REQUIRE(prec == PREC_BF16 || prec == PREC_BF16X3 || prec == PREC_F16X3, AWT_ERR_INVALID, "attention: precision must be bf16 (1), bf16x3 (3) or fp16x3 (4) here");
+  const int terms = prec_products(prec);
   AWT_REQUIRE(q_hi && k_hi && v_hi && (o_hi || o_f32), AWT_ERR_INVALID, "attention: null plane");
   AWT_REQUIRE(terms == 1 || (q_lo && k_lo && v_lo), AWT_ERR_INVALID, "attention: lo planes required for terms == 3");
   AttnArgs a{q_hi, q_lo, k_hi, k_lo, v_hi, v_lo, o_hi, o_lo, o_f32, lse, B, H, S};
@@ -326,6 +327,7 @@ int launch_attention(awt_ctx* c, const bf16_t* q_hi, const bf16_t* q_lo, const b
   // grids under one round, and grids whose last round would be mostly empty (Whisper-tiny at B = 32: 3 rounds vs 2.75).
   const int64_t wg2 = (int64_t)((S + 255) / 256) * B * H, wg1 = (int64_t)((S + 127) / 128) * B * H;
   const double cost2 = (double)((wg2 + 511) / 512), cost1 = 0.55 * (double)((wg1 + 511) / 512);
+  if (prec == PREC_F16X3) return cost1 < cost2 ? launch_t<3, 1, true>(a, s) : launch_t<3, 2, true>(a, s);
   if (cost1 < cost2) return terms == 3 ? launch_t<3, 1>(a, s) : launch_t<1, 1>(a, s);
   return terms == 3 ? launch_t<3, 2>(a, s) : launch_t<1, 2>(a, s);
 }

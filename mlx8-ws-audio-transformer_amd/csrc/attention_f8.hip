@@ -1,0 +1,344 @@
+// Flash-style self-attention forward (K10) in the f16f8 operand format (common.h PREC_F16F8) -- gfx950.
+//
+// Same structure as attention.hip (swapped first product S^T = K Q^T with the query on the lane, online softmax in the log2
+// domain, O^T += V^T P^T with the exponentiated accumulator tile as B operand, 64-key K/V tiles by 16-byte LDS-DMA, double
+// buffered), but every split product  a b ~ a_hi b_hi + a_hi b_lo + a_lo b_hi  issues
+//     a_hi b_hi               on v_mfma_f32_32x32x16_f16            (fp16 planes, 11 significant bits),
+//     a_hi b_lo + a_lo b_hi   on v_mfma_scale_f32_32x32x64_f8f6f4   (e4m3 planes with fixed power-of-two scales),
+// i.e. 8 + 4 MFMAs of 32 + 64 cycles per (64-key tile, 32-query tile) and product instead of 24 of 32: 2/3 of the matrix
+// pipe time of the split-bf16 kernel, at an error of 2^-16 instead of 2^-17 per product (DESIGN.md "Numerics").
+//
+// Operand images.  q, k, v arrive head-major [B, H, S, 64] as three planes each: fp16 (128-byte rows), hi8 and lo8 (64-byte
+// rows).  The contraction order of the scaled MFMA is free as long as both operands use the same lane -> k assignment
+// (tools/mx_probe3.hip), so:
+//   S^T cross terms: lane (row l & 31, half l >> 5) holds dims 32 half .. 32 half + 31 of its key (A) / query (B): 32
+//     contiguous bytes of a 64-byte row, two ds_read_b128 (K) or two global loads (Q, once per workgroup);
+//   O^T cross terms: the B operand is the lane's own 32 probabilities of the 64-key tile, byte 16 kt2 + r = accumulator
+//     register r of 32-key sub-tile kt2 = key 32 kt2 + (r & 3) + 8 (r >> 2) + 4 half; the A operand V8^T is gathered in
+//     exactly that key order by four ds_read_b64_tr_b8 per 32-dim tile (per 16-lane group a block of 8 rows x 16 bytes, lane
+//     2 q + p supplies the address of row q, bytes 8 p .. 8 p + 7, lane i receives column i with row q in byte q).
+#include <type_traits>
+#include "common.h"
+
+extern int g_attn_shape;
+
+namespace {
+
+constexpr int KB = 64;               // keys per tile
+constexpr int PL16 = KB * 64 * 2;    // 8 KiB: [64 keys][64 dims] fp16
+constexpr int PL8 = KB * 64;         // 4 KiB: [64 keys][64 dims] e4m3
+constexpr int STAGE = 2 * PL16 + 4 * PL8;   // K16 | V16 | K8 | Klo8 | V8 | Vlo8 = 32 KiB
+constexpr int OFF_K16 = 0, OFF_V16 = PL16, OFF_K8 = 2 * PL16, OFF_KL8 = 2 * PL16 + PL8, OFF_V8 = 2 * PL16 + 2 * PL8, OFF_VL8 = 2 * PL16 + 3 * PL8;
+
+struct Attn8Args {
+  const bf16_t *q16, *k16, *v16;                 // fp16 bits
+  const uint8_t *q8, *ql8, *k8, *kl8, *v8, *vl8;
+  bf16_t* o16; uint8_t *o8, *ol8; float* o_f32;  // output: f16f8 activation planes [B*S, H*64] or fp32
+  float* lse;
+  int B, H, S;
+};
+
+__device__ __forceinline__ int swz16(int row) { return (row >> 1) & 7; }        // fp16 planes: 128-byte rows, 8 chunks
+__device__ __forceinline__ int swz_k8(int row) { return (row >> 2) & 3; }       // K8 planes: 64-byte rows read by ds_read_b128
+__device__ __forceinline__ int swz_v8(int row) { return ((row >> 3) & 1) << 1; }   // V8 planes: rows k and k + 8 land in different 32-byte halves
+
+__device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ bf16x4 tr_read16(const char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)p);
+}
+__device__ __forceinline__ i32x2 tr_read8(const char* p) {
+  return __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) i32x2*)p);
+}
+
+// One K/V tile, global -> LDS.  The tile is 8 + 8 groups of 64 sixteen-byte slots in the fp16 planes and 4 groups in each of the
+// four e4m3 planes (an LDS-DMA instruction fills one group: wave-uniform base + lane * 16); wave w of NW takes groups w, w + NW, ...
+template <int NW>
+__device__ __forceinline__ void stage_kv(const Attn8Args& a, int64_t head_off, int kt, char* stage, int wave, int lane) {
+  const int64_t tile_off = head_off + (int64_t)kt * (KB * 64);
+  const int last = a.S - 1 - kt * KB;          // rows past the sequence end re-read its last key (masked in the tail tile)
+  const bf16_t* k16 = a.k16 + tile_off; const bf16_t* v16 = a.v16 + tile_off;
+#pragma unroll
+  for (int g0 = 0; g0 < 8; g0 += NW) {
+    const int grp = g0 + wave;
+    if (grp < 8) {
+      const int p = grp * 64 + lane;
+      const int row = p >> 3;
+      const unsigned off = (unsigned)(min(row, last) * 64 + (((p & 7) ^ swz16(row)) << 3));
+      char* dst = stage + grp * 1024;
+      glds16(k16 + off, dst + OFF_K16);
+      glds16(v16 + off, dst + OFF_V16);
+    }
+  }
+#pragma unroll
+  for (int g0 = 0; g0 < 4; g0 += NW) {
+    const int grp = g0 + wave;
+    if (grp < 4) {
+      const int p = grp * 64 + lane;
+      const int row = p >> 2, c = p & 3;
+      const int r = min(row, last);
+      const unsigned offk = (unsigned)(r * 64 + ((c ^ swz_k8(row)) << 4));
+      const unsigned offv = (unsigned)(r * 64 + ((c ^ swz_v8(row)) << 4));
+      char* dst = stage + grp * 1024;
+      glds16(a.k8 + tile_off + offk, dst + OFF_K8);
+      glds16(a.kl8 + tile_off + offk, dst + OFF_KL8);
+      glds16(a.v8 + tile_off + offv, dst + OFF_V8);
+      glds16(a.vl8 + tile_off + offv, dst + OFF_VL8);
+    }
+  }
+}
+
+// probabilities p in [0, 1] -> e4m3 of p 2^E without clamping (p 2^8 <= 256, (p - fp16(p)) 2^19 <= 128): the conversion
+// instruction applies the power-of-two scale itself (it divides by its scale operand)
+template <int E>
+__device__ __forceinline__ int fp8x4_scaled(float a, float b, float c, float d) {
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
+  constexpr float inv = pow2f(-E);
+  s16x2 r = {0, 0};
+  r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(r, a, b, inv, false);
+  r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(r, c, d, inv, true);
+  return __builtin_bit_cast(int, r);
+}
+
+template <int QT, int NW>
+__global__ __launch_bounds__(64 * NW, (QT == 1 && NW == 6) ? 3 : 2) void attention_f16f8_kernel(Attn8Args a) {
+  constexpr int QW = 32 * QT, QB = NW * QW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // XCD-aware 1-D grid (attention.hip): the query blocks of one head share an XCD's L2 copy of the head's K and V
+  const int nqb = (a.S + QB - 1) / QB;
+  const int nwg = nqb * a.B * a.H;
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int qd = nwg >> 3, rm = nwg & 7;
+  const int logical = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx;
+  const int bh = logical / nqb;
+  const int b = bh / a.H, h = bh - b * a.H;
+  const int q0 = (logical - bh * nqb) * QB + wave * QW;
+  const int64_t head_off = (int64_t)bh * a.S * 64;
+  const int ql = lane & 31, half = lane >> 5;
+
+  // ---- Q fragments: fp16 (lane holds Q[q][16 ks + 8 half + j]) and the two e4m3 operands (dims 32 half .. + 31)
+  bf16x8 q16[QT][4];
+  i32x8 q8[QT], ql8[QT];
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    int q = q0 + 32 * t + ql; q = q < a.S ? q : a.S - 1;
+    const int64_t off = head_off + (int64_t)q * 64;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) q16[t][ks] = *reinterpret_cast<const bf16x8*>(a.q16 + off + half * 8 + ks * 16);
+    const uint4 x0 = *reinterpret_cast<const uint4*>(a.q8 + off + half * 32), x1 = *reinterpret_cast<const uint4*>(a.q8 + off + half * 32 + 16);
+    const uint4 y0 = *reinterpret_cast<const uint4*>(a.ql8 + off + half * 32), y1 = *reinterpret_cast<const uint4*>(a.ql8 + off + half * 32 + 16);
+    q8[t] = (i32x8){(int)x0.x, (int)x0.y, (int)x0.z, (int)x0.w, (int)x1.x, (int)x1.y, (int)x1.z, (int)x1.w};
+    ql8[t] = (i32x8){(int)y0.x, (int)y0.y, (int)y0.z, (int)y0.w, (int)y1.x, (int)y1.y, (int)y1.z, (int)y1.w};
+  }
+
+  f32x16 oacc[QT][2];
+  float m_run[QT], l_run[QT];
+#pragma unroll
+  for (int t = 0; t < QT; ++t) { oacc[t][0] = (f32x16){}; oacc[t][1] = (f32x16){}; m_run[t] = -1.0e30f; l_run[t] = 0.f; }
+
+  // ---- loop-invariant LDS byte offsets
+  //   K16 fragment (row = 32 kt2 + ql, chunk 2 ks + half): koff[ks] + 4096 kt2          (as attention.hip)
+  //   K8 fragment (row = 32 kt2 + ql, chunks 2 half, 2 half + 1): k8off[c] + 2048 kt2    (swz_k8 repeats every 16 rows)
+  //   V16^T blocks: voff / voffx as attention.hip
+  //   V8^T blocks (read n = 0..3 covers operand bytes 8 n .. 8 n + 7): row = 16 n + 8 (q >> 2) + (q & 3) + 4 half_of_group,
+  //     16-byte chunk (g & 1) + 2 et, XOR 2 (q >> 2):  v8off + 1024 n, dim-tile et toggles byte bit 5
+  int koff[4], k8off[2];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) koff[ks] = ql * 128 + (((2 * ks + half) ^ swz16(ql)) << 4);
+#pragma unroll
+  for (int c = 0; c < 2; ++c) k8off[c] = ql * 64 + (((2 * half + c) ^ swz_k8(ql)) << 4);
+  const int g = lane >> 4, li = lane & 15, qq = li >> 2, pp = li & 3;
+  const int vkey = 4 * (g >> 1) + qq;
+  const int voff = vkey * 128 + (((2 * (g & 1) + (pp >> 1)) ^ swz16(vkey)) << 4) + 8 * (pp & 1);
+  const int voffx = voff ^ 64;
+  const int tq = li >> 1, tp = li & 1;
+  const int v8key = 8 * (tq >> 2) + (tq & 3) + 4 * (g >> 1);
+  const int v8off = v8key * 64 + ((((g & 1)) ^ swz_v8(v8key)) << 4) + 8 * tp;
+
+  const int ntiles = (a.S + KB - 1) / KB;
+  stage_kv<NW>(a, head_off, 0, smem, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  auto tile = [&](auto tail_t, int kt) {
+    constexpr bool TAIL = decltype(tail_t)::value;
+    const char* cur = smem + (kt & 1) * STAGE;
+    if (kt + 1 < ntiles) stage_kv<NW>(a, head_off, kt + 1, smem + ((kt + 1) & 1) * STAGE, wave, lane);
+
+    // ---- S^T = K Q^T
+    f32x16 sacc[QT][2];
+#pragma unroll
+    for (int kt2 = 0; kt2 < 2; ++kt2) {
+#pragma unroll
+      for (int t = 0; t < QT; ++t) sacc[t][kt2] = (f32x16){};
+      {
+        const uint4 x0 = *reinterpret_cast<const uint4*>(cur + OFF_K8 + k8off[0] + kt2 * 2048), x1 = *reinterpret_cast<const uint4*>(cur + OFF_K8 + k8off[1] + kt2 * 2048);
+        const uint4 y0 = *reinterpret_cast<const uint4*>(cur + OFF_KL8 + k8off[0] + kt2 * 2048), y1 = *reinterpret_cast<const uint4*>(cur + OFF_KL8 + k8off[1] + kt2 * 2048);
+        const i32x8 k8 = {(int)x0.x, (int)x0.y, (int)x0.z, (int)x0.w, (int)x1.x, (int)x1.y, (int)x1.z, (int)x1.w};
+        const i32x8 kl8 = {(int)y0.x, (int)y0.y, (int)y0.z, (int)y0.w, (int)y1.x, (int)y1.y, (int)y1.z, (int)y1.w};
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+          sacc[t][kt2] = mfma32_f8<e8m0(-kF8KV), e8m0(-kF8Q - kF8Lo)>(k8, ql8[t], sacc[t][kt2]);
+          sacc[t][kt2] = mfma32_f8<e8m0(-kF8KV - kF8Lo), e8m0(-kF8Q)>(kl8, q8[t], sacc[t][kt2]);
+        }
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 kh = *reinterpret_cast<const bf16x8*>(cur + OFF_K16 + koff[ks] + kt2 * 4096);
+#pragma unroll
+        for (int t = 0; t < QT; ++t) sacc[t][kt2] = mfma32<true>(kh, q16[t][ks], sacc[t][kt2]);
+      }
+    }
+
+    // ---- online softmax, then the accumulator tile becomes the three P operands in place
+    bf16x8 p16[QT][4];        // fp16 B fragments of k-steps (kt2, s2): registers 8 s2 .. 8 s2 + 7 of sub-tile kt2
+    i32x8 p8[QT], pl8[QT];    // e4m3 operands: byte 16 kt2 + r
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+      float tmax = -1.0e30f;
+#pragma unroll
+      for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          if (TAIL) {
+            const int key = kt * KB + kt2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            sacc[t][kt2][r] = key < a.S ? sacc[t][kt2][r] : -1.0e30f;
+          }
+          tmax = fmaxf(tmax, sacc[t][kt2][r]);
+        }
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+      const float m_new = fmaxf(m_run[t], tmax);
+      const float alpha = __builtin_amdgcn_exp2f(m_run[t] - m_new);
+      m_run[t] = m_new;
+      float psum = 0.f;
+#pragma unroll
+      for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          float pv[4], lo[4]; bf16_t hb[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            pv[j] = __builtin_amdgcn_exp2f(sacc[t][kt2][4 * r4 + j] - m_new);
+            psum += pv[j];
+            hb[j] = f32_to_f16(pv[j]);
+            lo[j] = __builtin_fmaf(f16_to_f32(hb[j]), -1.0f, pv[j]);
+            p16[t][2 * kt2 + (r4 >> 1)][4 * (r4 & 1) + j] = (short)hb[j];
+          }
+          p8[t][4 * kt2 + r4] = fp8x4_scaled<kF8P>(pv[0], pv[1], pv[2], pv[3]);
+          pl8[t][4 * kt2 + r4] = fp8x4_scaled<kF8P + kF8Lo>(lo[0], lo[1], lo[2], lo[3]);
+        }
+      l_run[t] = l_run[t] * alpha + psum;
+#pragma unroll
+      for (int et = 0; et < 2; ++et)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[t][et][r] *= alpha;
+    }
+
+    // ---- O^T += V^T P^T : fp16 part (k-steps of 16 keys, V16^T by ds_read_b64_tr_b16) ...
+#pragma unroll
+    for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int et = 0; et < 2; ++et) {
+          const int cst = kt2 * 4096 + s2 * 2048;
+          const int off0 = (et == 0 ? voff : voffx) + cst;
+          const int off1 = (et == 0 ? voffx : voff) + cst + 1024;
+          const bf16x4 va = tr_read16(cur + OFF_V16 + off0), vb = tr_read16(cur + OFF_V16 + off1);
+          const bf16x8 vh = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
+#pragma unroll
+          for (int t = 0; t < QT; ++t) oacc[t][et] = mfma32<true>(vh, p16[t][2 * kt2 + s2], oacc[t][et]);
+        }
+    // ---- ... and the two cross terms on the scaled e4m3 MFMA (one instruction covers the tile's 64 keys)
+#pragma unroll
+    for (int et = 0; et < 2; ++et) {
+      i32x8 v8, vl8;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        const int off = (v8off ^ (et << 5)) + n * 1024;
+        const i32x2 x = tr_read8(cur + OFF_V8 + off), y = tr_read8(cur + OFF_VL8 + off);
+        v8[2 * n] = x[0]; v8[2 * n + 1] = x[1];
+        vl8[2 * n] = y[0]; vl8[2 * n + 1] = y[1];
+      }
+#pragma unroll
+      for (int t = 0; t < QT; ++t) {
+        oacc[t][et] = mfma32_f8<e8m0(-kF8KV), e8m0(-kF8P - kF8Lo)>(v8, pl8[t], oacc[t][et]);
+        oacc[t][et] = mfma32_f8<e8m0(-kF8KV - kF8Lo), e8m0(-kF8P)>(vl8, p8[t], oacc[t][et]);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  };
+  for (int kt = 0; kt + 1 < ntiles; ++kt) tile(std::false_type{}, kt);
+  if (a.S % KB) tile(std::true_type{}, ntiles - 1);
+  else tile(std::false_type{}, ntiles - 1);
+
+  // ---- normalise and store: lane holds query (lane & 31) of each query tile, dims (r & 3) + 8 (r >> 2) + 4 half
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    const float l_tot = l_run[t] + __shfl_xor(l_run[t], 32);
+    const float inv = 1.0f / l_tot;
+    const int q = q0 + 32 * t + ql;
+    if (a.lse && q < a.S && half == 0) a.lse[(int64_t)bh * a.S + q] = m_run[t] + __builtin_amdgcn_logf(l_tot);
+    if (q < a.S) {
+      const int64_t row = ((int64_t)b * a.S + q) * (a.H * 64) + h * 64;
+#pragma unroll
+      for (int et = 0; et < 2; ++et)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int e = 32 * et + 8 * g4 + 4 * half;
+          float v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = oacc[t][et][4 * g4 + j] * inv;
+          if (a.o_f32) {
+            *reinterpret_cast<float4*>(a.o_f32 + row + e) = make_float4(v[0], v[1], v[2], v[3]);
+          } else {
+            uint2 h16; unsigned hi8, lo8;
+            f16f8x4<kF8Act>(v, h16, hi8, lo8);
+            *reinterpret_cast<uint2*>(a.o16 + row + e) = h16;
+            *reinterpret_cast<unsigned*>(a.o8 + row + e) = hi8;
+            *reinterpret_cast<unsigned*>(a.ol8 + row + e) = lo8;
+          }
+        }
+    }
+  }
+}
+
+template <int QT, int NW>
+int launch_t(const Attn8Args& a, hipStream_t s) {
+  constexpr int lds = 2 * STAGE;
+  constexpr int QB = NW * 32 * QT;
+  AWT_ONCE_PER_DEVICE(AWT_HIP_CHECK(hipFuncSetAttribute((const void*)attention_f16f8_kernel<QT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)));
+  dim3 grid(((a.S + QB - 1) / QB) * a.B * a.H);
+  hipLaunchKernelGGL((attention_f16f8_kernel<QT, NW>), grid, dim3(64 * NW), lds, s, a);
+  AWT_HIP_CHECK(hipGetLastError());
+  return AWT_OK;
+}
+
+}  // namespace
+
+int g_attn_shape = 0;
+void awt_attn_force_shape(int v) { g_attn_shape = v; }
+
+int launch_attention_f16f8(awt_ctx* c, const F8Planes& q, const F8Planes& k, const F8Planes& v, const F8Planes& o, float* o_f32,
+                           float* lse, int B, int H, int S, hipStream_t s) {
+  AWT_REQUIRE(B > 0 && H > 0 && S > 0, AWT_ERR_INVALID, "attention: bad shape");
+  AWT_REQUIRE(q.p16 && q.hi8 && q.lo8 && k.p16 && k.hi8 && k.lo8 && v.p16 && v.hi8 && v.lo8, AWT_ERR_INVALID, "attention (f16f8): null plane");
+  AWT_REQUIRE(o_f32 || (o.p16 && o.hi8 && o.lo8), AWT_ERR_INVALID, "attention (f16f8): null output plane");
+  Attn8Args a{q.p16, k.p16, v.p16, q.hi8, q.lo8, k.hi8, k.lo8, v.hi8, v.lo8, o.p16, o.hi8, o.lo8, o_f32, lse, B, H, S};
+  ProfScope prof(c, AWT_PROF_ATTENTION, s, 4.0 * (double)B * H * (double)S * S * 64);
+  // shapes (awt_tuning_set "attn_shape"): 0 = auto; 1 = 4 waves x 32 queries; 2 = 4 waves x 64 queries; 3 = 6 waves x 32 queries
+  // (three waves per SIMD: one wave's softmax VALU work runs beside the others' MFMAs)
+  const int shape = g_attn_shape;
+  if (shape == 1) return launch_t<1, 4>(a, s);
+  if (shape == 2) return launch_t<2, 4>(a, s);
+  if (shape == 3) return launch_t<1, 6>(a, s);
+  const int64_t wg6 = (int64_t)((S + 191) / 192) * B * H, wg1 = (int64_t)((S + 127) / 128) * B * H;
+  const double cost6 = (double)((wg6 + 511) / 512), cost1 = 0.7 * (double)((wg1 + 511) / 512);
+  if (cost1 < cost6) return launch_t<1, 4>(a, s);
+  return launch_t<1, 6>(a, s);
+}

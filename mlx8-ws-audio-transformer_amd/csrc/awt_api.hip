@@ -45,6 +45,11 @@ extern "C" int awt_tuning_set(const char* key, int value) {
     awt_gemm_force_tile(value);
     return AWT_OK;
   }
+  if (!strcmp(key, "attn_shape")) {
+    AWT_REQUIRE(value >= 0 && value <= 3, AWT_ERR_INVALID, "tuning_set: attn_shape must be 0 (auto), 1, 2 or 3");
+    awt_attn_force_shape(value);
+    return AWT_OK;
+  }
   AWT_REQUIRE(false, AWT_ERR_INVALID, "tuning_set: unknown key");
 }
 
@@ -657,8 +662,16 @@ extern "C" int awt_op_attention(awt_ctx* c, const float* q, const float* k, cons
   bf16_t* pl[6];
   for (int i = 0; i < 6; ++i) pl[i] = (bf16_t*)((char*)workspace + i * pb);
   const float* src[3] = {q, k, v};
-  for (int i = 0; i < 3; ++i) {   // the kernel expects q * log2(e)
-    int rc = launch_split_f32(c, src[i], n, i == 0 ? 1.4426950408889634f : 1.0f, pl[2 * i], pl[2 * i + 1], s); if (rc) return rc;
+  const int f8exp[3] = {kF8Q, kF8KV, kF8KV};
+  for (int i = 0; i < 3; ++i) {   // the kernel expects q * log2(e); f16f8: the second 2-byte plane holds the two e4m3 planes
+    uint8_t* b8 = (uint8_t*)pl[2 * i + 1];
+    int rc = launch_split_planes(c, src[i], n, i == 0 ? 1.4426950408889634f : 1.0f, terms, f8exp[i], pl[2 * i], pl[2 * i + 1], b8, b8 + n, s);
+    if (rc) return rc;
+  }
+  if (terms == PREC_F16F8) {
+    F8Planes P[3];
+    for (int i = 0; i < 3; ++i) P[i] = F8Planes{pl[2 * i], (uint8_t*)pl[2 * i + 1], (uint8_t*)pl[2 * i + 1] + n};
+    return launch_attention_f16f8(c, P[0], P[1], P[2], F8Planes{nullptr, nullptr, nullptr}, o, nullptr, B, H, S, s);
   }
   return launch_attention(c, pl[0], pl[1], pl[2], pl[3], pl[4], pl[5], nullptr, nullptr, o, nullptr, B, H, S, terms, s);
 }

@@ -13,7 +13,32 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+
 #define AWT_WAVE 64
+
+// ---------------------------------------------------------------- operand precisions (awt_encoder_cfg.mfma_terms, `terms` of the operators)
+//   PREC_BF16    one bf16 plane, one MFMA per fragment pair (fast, ~4e-3 rel-L2)
+//   PREC_BF16X3  bf16 hi + lo planes, three MFMAs: a_hi b_lo + a_lo b_hi + a_hi b_hi  (2^-17 per operand)
+//   PREC_F16X3   the same with fp16 planes (11 + 11 significant bits: 2^-23 per operand; operands must stay inside fp16's range)
+//   PREC_F16F8   fp16 plane + two e4m3 planes: a_hi b_hi on the fp16 MFMA, the two cross terms a_hi b_lo + a_lo b_hi on the
+//                block-scaled fp8 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4, twice the fp16 rate): two MFMA-equivalents per
+//                fragment pair instead of three.  hi8 = e4m3(x 2^s), lo8 = e4m3((x - fp16(x)) 2^(s + 11)) with a FIXED
+//                power-of-two s per operand role (below), so no reduction pass is needed to write a plane.
+enum { PREC_BF16 = 1, PREC_BF16X3 = 3, PREC_F16X3 = 4, PREC_F16F8 = 5 };
+__host__ __device__ constexpr bool prec_is_f16(int p) { return p == PREC_F16X3 || p == PREC_F16F8; }
+__host__ __device__ constexpr int prec_products(int p) { return p == PREC_BF16 ? 1 : 3; }   // split products formed (cross terms may be fp8)
+// fixed exponents of the e4m3 planes: |x| 2^s must stay <= 448 (saturates beyond); values below 2^(-6 - s) are subnormal
+// (absolute error 2^(-10 - s)), which is far below the cross terms' weight in any dot product they enter
+constexpr int kF8Act = -2;     // GEMM A operands (LayerNorm / attention / GELU outputs, im2col rows, LoRA u): |x| <= 1792
+constexpr int kF8Wgt = 4;      // GEMM W operands: |w| <= 28
+constexpr int kF8Q = 2;        // attention q (already scaled by head_dim^-1/2 log2 e): |q| <= 112
+constexpr int kF8KV = 0;       // attention k, v: |x| <= 448
+constexpr int kF8P = 8;        // attention probabilities exp2(s - max) in (0, 1]
+constexpr int kF8Lo = 11;      // lo planes carry (x - fp16(x)) 2^(s + 11): |x - fp16(x)| <= 2^-11 |x|
+__host__ __device__ constexpr int e8m0(int exp2) { return 127 + exp2; }   // E8M0 scale byte of 2^exp2
 
 // ---------------------------------------------------------------- bf16 helpers (device)
 __device__ __forceinline__ bf16_t f32_to_bf16(float x) {
@@ -30,6 +55,56 @@ __device__ __forceinline__ void split_bf16(float x, bf16_t& hi, bf16_t& lo) {
   lo = f32_to_bf16(x - bf16_to_f32(hi));
 }
 __device__ __forceinline__ unsigned pack2(bf16_t a, bf16_t b) { return (unsigned)a | ((unsigned)b << 16); }
+
+// ---------------------------------------------------------------- fp16 / fp8 helpers (device)
+__device__ __forceinline__ bf16_t f32_to_f16(float x) { _Float16 h = (_Float16)x; return __builtin_bit_cast(bf16_t, h); }   // RNE
+__device__ __forceinline__ float f16_to_f32(bf16_t b) { return (float)__builtin_bit_cast(_Float16, b); }
+// hi + lo split on a 16-bit carrier: bf16 planes (F16 = false) or fp16 planes (F16 = true)
+template <bool F16>
+__device__ __forceinline__ void split16(float x, bf16_t& hi, bf16_t& lo) {
+  if constexpr (F16) { hi = f32_to_f16(x); lo = f32_to_f16(x - f16_to_f32(hi)); }
+  else split_bf16(x, hi, lo);
+}
+template <bool F16>
+__device__ __forceinline__ float join16(bf16_t hi, bf16_t lo) { return F16 ? f16_to_f32(hi) + f16_to_f32(lo) : bf16_to_f32(hi) + bf16_to_f32(lo); }
+template <bool F16>
+__device__ __forceinline__ float cvt16(bf16_t v) { return F16 ? f16_to_f32(v) : bf16_to_f32(v); }
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+template <bool F16>
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+// block-scaled e4m3 x e4m3 product with one power-of-two scale per operand (E8M0 bytes SA, SB)
+template <int SA, int SB>
+__device__ __forceinline__ f32x16 mfma32_f8(i32x8 a, i32x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, SA, 0, SB);
+}
+__host__ __device__ constexpr float pow2f(int e) { return e >= 0 ? (float)(1ull << e) : 1.0f / (float)(1ull << -e); }
+// four floats -> four e4m3 bytes of x 2^S (round to nearest even; v_cvt_pk_fp8_f32 turns |x| > 464 into NaN, so clamp first)
+template <int S>
+__device__ __forceinline__ unsigned fp8x4(float a, float b, float c, float d) {
+  constexpr float sc = pow2f(S);
+  a = __builtin_amdgcn_fmed3f(a * sc, -448.f, 448.f); b = __builtin_amdgcn_fmed3f(b * sc, -448.f, 448.f);
+  c = __builtin_amdgcn_fmed3f(c * sc, -448.f, 448.f); d = __builtin_amdgcn_fmed3f(d * sc, -448.f, 448.f);
+  int r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+  r = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
+  return (unsigned)r;
+}
+// the three planes of four consecutive f16f8 elements: fp16 bits (two dwords), hi8 dword, lo8 dword
+template <int S>
+__device__ __forceinline__ void f16f8x4(const float (&v)[4], uint2& h16, unsigned& hi8, unsigned& lo8) {
+  bf16_t h[4]; float l[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) { h[t] = f32_to_f16(v[t]); l[t] = v[t] - f16_to_f32(h[t]); }
+  h16 = make_uint2(pack2(h[0], h[1]), pack2(h[2], h[3]));
+  hi8 = fp8x4<S>(v[0], v[1], v[2], v[3]);
+  lo8 = fp8x4<S + kF8Lo>(l[0], l[1], l[2], l[3]);
+}
 
 // erf to 1.5e-7 absolute (Abramowitz & Stegun 7.1.26: five-term polynomial in 1 / (1 + p |x|) times exp(-x^2)) in ~12
 // instructions; libm's erff costs ~3x that, and the MLP GEMM epilogue evaluates 295 M of them per layer at B = 64.
@@ -154,6 +229,13 @@ int launch_attention(awt_ctx* c, const bf16_t* q_hi, const bf16_t* q_lo, const b
                      const bf16_t* v_hi, const bf16_t* v_lo, bf16_t* o_hi, bf16_t* o_lo, float* o_f32, float* lse, int B, int H,
                      int S, int terms, hipStream_t s);
 int launch_split_f32(awt_ctx* c, const float* x, int64_t n, float scale, bf16_t* hi, bf16_t* lo, hipStream_t s);
+// precision-aware form: PREC_BF16 / PREC_BF16X3 / PREC_F16X3 write p16 (+ lo16); PREC_F16F8 writes p16 (fp16), hi8 = e4m3(x 2^f8_exp),
+// lo8 = e4m3((x - fp16(x)) 2^(f8_exp + 11))
+struct F8Planes { bf16_t* p16; uint8_t* hi8; uint8_t* lo8; };
+int launch_split_planes(awt_ctx* c, const float* x, int64_t n, float scale, int prec, int f8_exp, bf16_t* p16, bf16_t* lo16, uint8_t* hi8,
+                        uint8_t* lo8, hipStream_t s);
+int launch_attention_f16f8(awt_ctx* c, const F8Planes& q, const F8Planes& k, const F8Planes& v, const F8Planes& o, float* o_f32,
+                           float* lse, int B, int H, int S, hipStream_t s);
 // weights: dst(row_off + n, col_off + k) = scale * src[n, c, dt], k = dt * C + c (taps = 1: plain [N, C]); dst is a
 // fragment-major matrix with ld / 32 k-steps (ld = its K, a multiple of 32; its row count a multiple of 16)
 int launch_pack_weight(awt_ctx* c, const float* src, int N, int C, int taps, int64_t ld, int row_off, int col_off, float scale,
@@ -169,6 +251,7 @@ int prepare_waveform_impl(awt_ctx* c, const void* pcm, int pcm_is_i16, int chann
                           int n_in, int sr_in, int sr_out, float* out, int n_out, hipStream_t s);
 int64_t resampled_length(int n_in, int sr_in, int sr_out);
 void awt_free_tables(awt_ctx* c);
+void awt_attn_force_shape(int v);   // f16f8 attention workgroup shape: 0 auto, 1 / 2 / 3 (attention_f8.hip)
 void awt_gemm_force_tile(int t);  // 0 auto, 64 / 128 / 256: tuning / tests (awt_tuning_set)
 
 // ---- backward-pass launchers

@@ -72,6 +72,29 @@ __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ x,
   }
 }
 
+template <int PREC>
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, int64_t n4, float scale, float f8_scale, bf16_t* p16,
+                                                           bf16_t* lo16, uint8_t* hi8, uint8_t* lo8) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 q = reinterpret_cast<const float4*>(x)[i];
+    const float v[4] = {q.x * scale, q.y * scale, q.z * scale, q.w * scale};
+    bf16_t h[4], l[4];
+    if constexpr (PREC == PREC_F16F8) {
+      float lo[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { h[t] = f32_to_f16(v[t]); lo[t] = (v[t] - f16_to_f32(h[t])) * (f8_scale * pow2f(kF8Lo)); }
+      reinterpret_cast<uint2*>(p16)[i] = make_uint2(pack2(h[0], h[1]), pack2(h[2], h[3]));
+      reinterpret_cast<unsigned*>(hi8)[i] = fp8x4<0>(v[0] * f8_scale, v[1] * f8_scale, v[2] * f8_scale, v[3] * f8_scale);
+      reinterpret_cast<unsigned*>(lo8)[i] = fp8x4<0>(lo[0], lo[1], lo[2], lo[3]);
+    } else {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) split16<PREC == PREC_F16X3>(v[t], h[t], l[t]);
+      reinterpret_cast<uint2*>(p16)[i] = make_uint2(pack2(h[0], h[1]), pack2(h[2], h[3]));
+      if (lo16) reinterpret_cast<uint2*>(lo16)[i] = make_uint2(pack2(l[0], l[1]), pack2(l[2], l[3]));
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ weight packing
 // dst(row_off + n, col_off + k) = src[n, c, dt] * scale with k = dt * C + c  (conv weights [N, C, taps] -> implicit-GEMM
 // rows; taps = 1 is a plain [N, C] linear weight), written in the fragment-major layout of w_frag_index().  Only the
@@ -314,6 +337,23 @@ int launch_split_f32(awt_ctx* c, const float* x, int64_t n, float scale, bf16_t*
   const int64_t n4 = n / 4;
   int grid = (int)((n4 + 255) / 256); if (grid > 4096) grid = 4096;
   hipLaunchKernelGGL(split_kernel, dim3(grid), dim3(256), 0, s, x, n4, scale, hi, lo);
+  AWT_HIP_CHECK(hipGetLastError());
+  return AWT_OK;
+}
+
+int launch_split_planes(awt_ctx* c, const float* x, int64_t n, float scale, int prec, int f8_exp, bf16_t* p16, bf16_t* lo16, uint8_t* hi8,
+                        uint8_t* lo8, hipStream_t s) {
+  AWT_REQUIRE(x && p16 && n > 0 && n % 4 == 0, AWT_ERR_INVALID, "split: n must be a positive multiple of 4");
+  AWT_REQUIRE(prec == PREC_BF16 || prec == PREC_BF16X3 || prec == PREC_F16X3 || prec == PREC_F16F8, AWT_ERR_INVALID, "split: unknown precision");
+  AWT_REQUIRE(prec != PREC_F16F8 || (hi8 && lo8), AWT_ERR_INVALID, "split: f16f8 needs both e4m3 planes");
+  AWT_REQUIRE(f8_exp >= -20 && f8_exp <= 20, AWT_ERR_INVALID, "split: bad e4m3 exponent");
+  ProfScope prof(c, AWT_PROF_OTHER, s, 0.0);
+  const int64_t n4 = n / 4;
+  int grid = (int)((n4 + 255) / 256); if (grid > 4096) grid = 4096;
+  const float f8s = f8_exp >= 0 ? (float)(1u << f8_exp) : 1.0f / (float)(1u << -f8_exp);
+  if (prec == PREC_F16F8) hipLaunchKernelGGL(split_planes_kernel<PREC_F16F8>, dim3(grid), dim3(256), 0, s, x, n4, scale, f8s, p16, lo16, hi8, lo8);
+  else if (prec == PREC_F16X3) hipLaunchKernelGGL(split_planes_kernel<PREC_F16X3>, dim3(grid), dim3(256), 0, s, x, n4, scale, f8s, p16, lo16, hi8, lo8);
+  else hipLaunchKernelGGL(split_planes_kernel<PREC_BF16X3>, dim3(grid), dim3(256), 0, s, x, n4, scale, f8s, p16, prec == PREC_BF16 ? nullptr : lo16, hi8, lo8);
   AWT_HIP_CHECK(hipGetLastError());
   return AWT_OK;
 }

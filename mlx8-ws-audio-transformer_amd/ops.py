@@ -8,7 +8,7 @@ import torch
 
 from . import _lib
 
-_TERMS = {"bf16": 1, "bf16x3": 3}
+_TERMS = {"bf16": 1, "bf16x3": 3, "fp16x3": 4, "f16f8": 5}   # common.h PREC_*
 
 
 def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, precision: str = "bf16x3") -> torch.Tensor:

@@ -58,8 +58,12 @@ def test_layernorm(d):
     assert (y - ref).abs().max().item() < 5e-6
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
-@pytest.mark.parametrize("B,H,S", [(1, 2, 64), (2, 3, 200), (1, 2, 1500), (1, 1, 129)])
+# max-abs error bound of softmax(q k^T) v vs float64 on these inputs, per operand precision
+ATT_TOL = {"bf16x3": 1e-4, "fp16x3": 2e-5, "f16f8": 2e-4, "bf16": 4e-2}
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16", "fp16x3", "f16f8"])
+@pytest.mark.parametrize("B,H,S", [(1, 2, 64), (2, 3, 200), (1, 2, 1500), (1, 1, 129), (3, 2, 257)])
 def test_attention(precision, B, H, S):
     from mlx8_ws_audio_transformer_amd import ops
     q, k, v = _rand((B, H, S, 64), 7, 0.35), _rand((B, H, S, 64), 8), _rand((B, H, S, 64), 9)
@@ -67,20 +71,39 @@ def test_attention(precision, B, H, S):
     p = torch.softmax(q.double() @ k.double().transpose(2, 3), dim=-1)
     ref = (p @ v.double()).transpose(1, 2).reshape(B, S, H * 64)
     err = (o.double() - ref).abs().max().item()
-    assert err < (1e-4 if precision == "bf16x3" else 4e-2), err  # v_exp_f32 ~1 ulp; bf16 rounds q, k, v and P
+    print(precision, (B, H, S), "max-abs", err)
+    assert err < ATT_TOL[precision], err  # v_exp_f32 ~1 ulp; bf16 rounds q, k, v and P
 
 
-def test_attention_online_softmax_rescale_branch():
+@pytest.mark.parametrize("shape", [1, 2, 3])
+def test_attention_f16f8_workgroup_shapes(shape):
+    """Every workgroup shape of the f16f8 attention kernel (4 x 32, 4 x 64, 6 x 32 queries) on a sequence with a tail tile."""
+    from mlx8_ws_audio_transformer_amd import _lib, ops
+    B, H, S = 2, 2, 333
+    q, k, v = _rand((B, H, S, 64), 17, 0.35), _rand((B, H, S, 64), 18), _rand((B, H, S, 64), 19)
+    _lib.tuning_set("attn_shape", shape)
+    try:
+        o = ops.attention(q, k, v, "f16f8")
+    finally:
+        _lib.tuning_set("attn_shape", 0)
+    p = torch.softmax(q.double() @ k.double().transpose(2, 3), dim=-1)
+    ref = (p @ v.double()).transpose(1, 2).reshape(B, S, H * 64)
+    assert (o.double() - ref).abs().max().item() < ATT_TOL["f16f8"]
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "fp16x3", "f16f8"])
+def test_attention_online_softmax_rescale_branch(precision):
     # one key per late tile dominates one query's row: forces the running maximum to jump tile after tile
     from mlx8_ws_audio_transformer_amd import ops
     B, H, S = 1, 1, 448
     q, k, v = _rand((B, H, S, 64), 10, 0.2), _rand((B, H, S, 64), 11), _rand((B, H, S, 64), 12)
     for t, key in enumerate([70, 150, 260, 390]):
         k[0, 0, key] = q[0, 0, 5] * (20.0 + 15 * t)
-    o = ops.attention(q, k, v, "bf16x3")
+    o = ops.attention(q, k, v, precision)
     p = torch.softmax(q.double() @ k.double().transpose(2, 3), dim=-1)
     ref = (p @ v.double()).transpose(1, 2).reshape(B, S, 64)
-    assert (o.double() - ref).abs().max().item() < 3e-4  # logits reach ~170: fp32 ulp of the exp2 argument is ~1.5e-5
+    # logits reach ~170: fp32 ulp of the exp2 argument is ~1.5e-5; f16f8 carries the logits to 2^-16 relative: 170 * 2^-16 = 2.6e-3 in the exponent
+    assert (o.double() - ref).abs().max().item() < (3e-4 if precision != "f16f8" else 1.5e-2)
 
 
 def test_linear_output_larger_than_2g_elements():
