@@ -44,7 +44,7 @@ PEAK_BF16_DENSE_TFLOPS = 2500.0   # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.
 GEMM_ALGO_BYTES_PER_STEP = 12 * 5.31e9 + 1.7e9
 ENCODER_GFLOP_PER_CLIP = {("small", False): 344.16, ("small", True): 36.30, ("tiny", False): 36.94, ("tiny", True): 3.33,
                           ("base", False): 87.37}
-PRECISIONS = ["bf16x3", "bf16"]
+PRECISIONS = ["f16f8", "fp16x3", "bf16x3", "bf16"]
 
 
 def parse():

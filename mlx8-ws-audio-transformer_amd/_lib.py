@@ -31,7 +31,7 @@ class EncoderCfg(C.Structure):
                 ("lora_alpha", C.c_float), ("lora_targets", C.c_uint32), ("chunk_clips", C.c_int32), ("training", C.c_int32), ("backward_terms", C.c_int32)]
 
 
-MFMA_PER_PAIR = {"bf16": 1, "bf16x3": 3}   # MFMA-equivalents issued per fragment pair, by precision mode
+MFMA_PER_PAIR = {"bf16": 1, "bf16x3": 3, "fp16x3": 3, "f16f8": 2}   # MFMA-equivalents issued per fragment pair, by precision mode
 BWD_ACCUMULATE, BWD_ALLREDUCE = 1, 2
 COMM_ID_BYTES = 128
 LORA_BITS = {"q_proj": 1, "k_proj": 2, "v_proj": 4, "out_proj": 8, "fc1": 16, "fc2": 32}

@@ -143,8 +143,8 @@ extern "C" int awt_prepare_waveform(awt_ctx* c, const void* pcm, int pcm_is_i16,
 // ------------------------------------------------------------------------------------------------ encoder
 namespace {
 
-struct Planes {  // a bf16 matrix as hi (+ lo) planes owned by the library
-  bf16_t* hi = nullptr; bf16_t* lo = nullptr; int64_t rows = 0, ld = 0;
+struct Planes {  // a weight matrix as operand planes owned by the library: hi (+ lo); f16f8: hi = fp16, lo = hi8 and x8 = lo8 planes
+  bf16_t* hi = nullptr; bf16_t* lo = nullptr; uint8_t* x8 = nullptr; int64_t rows = 0, ld = 0;
 };
 struct Linear {
   Planes w; float* bias = nullptr; int N = 0, K = 0;
@@ -174,7 +174,8 @@ size_t align_up(size_t x) { return (x + kAlign - 1) & ~(kAlign - 1); }
 struct awt_encoder {
   awt_ctx* ctx = nullptr;
   awt_encoder_cfg cfg{};
-  int planes = 1;          // 1 (bf16) or 2 (hi + lo)
+  int planes = 1;          // 2-byte-per-element planes per matrix: 1 (bf16) or 2 (hi + lo; f16f8: fp16 + the two e4m3 planes)
+  int prec = PREC_BF16X3;  // operand precision of the forward pass (cfg.mfma_terms: common.h PREC_*)
   Linear conv1, conv2;
   float* pos = nullptr;    // [S, d]
   float *lnf_g = nullptr, *lnf_b = nullptr;
@@ -198,6 +199,7 @@ int alloc_planes(awt_encoder* e, Planes* pl, int64_t rows, int64_t ld) {
   pl->rows = rows; pl->ld = ld;
   int rc = dev_alloc(e, (void**)&pl->hi, (size_t)rows * ld * 2); if (rc) return rc;
   if (e->planes == 2) { rc = dev_alloc(e, (void**)&pl->lo, (size_t)rows * ld * 2); if (rc) return rc; }
+  if (e->prec == PREC_F16F8) pl->x8 = (uint8_t*)pl->lo + (size_t)rows * ld;
   return AWT_OK;
 }
 int alloc_linear(awt_encoder* e, Linear* l, int N, int K) {
@@ -245,28 +247,53 @@ Workspace carve(const awt_encoder* e, char* base, int Bc) {
   return w;
 }
 
-GemmSeg seg_plain(const bf16_t* a_hi, const bf16_t* a_lo, int64_t lda, const Planes& w, int64_t wcol, int K, int M) {
+// the two 2-byte planes of an activation buffer of `elems` elements as operand planes of precision `prec`
+Act make_act(bf16_t* p0, bf16_t* p1, size_t elems, int prec) {
+  Act a;
+  a.p16 = p0;
+  if (prec == PREC_F16F8) { a.hi8 = (uint8_t*)p1; a.lo8 = a.hi8 ? a.hi8 + elems : nullptr; }
+  else a.lo16 = p1;
+  return a;
+}
+Act act_offset(const Act& a, int64_t elems) {
+  Act r;
+  r.p16 = a.p16 + elems;
+  r.lo16 = a.lo16 ? a.lo16 + elems : nullptr;
+  r.hi8 = a.hi8 ? a.hi8 + elems : nullptr;
+  r.lo8 = a.lo8 ? a.lo8 + elems : nullptr;
+  return r;
+}
+void set_out(GemmOut& o, const Act& a) { o.hi = a.p16; o.lo = a.lo16; o.hi8 = a.hi8; o.lo8 = a.lo8; }
+
+GemmSeg seg_plain(const Act& a, int64_t lda, const Planes& w, int64_t wcol, int K, int M) {
   GemmSeg s{};
-  s.a_hi = a_hi; s.a_lo = a_lo; s.lda = lda;
-  s.w_hi = w.hi; s.w_lo = w.lo; s.w_ksteps = (int)(w.ld / 32); s.w_k0 = (int)(wcol / 32); s.K = K;
+  s.a_hi = a.p16; s.a_lo = a.lo16; s.a8 = a.hi8; s.al8 = a.lo8; s.lda = lda;
+  s.w_hi = w.hi; s.w_lo = w.lo; s.w8 = (const uint8_t*)w.lo; s.wl8 = w.x8;
+  s.w_ksteps = (int)(w.ld / 32); s.w_k0 = (int)(wcol / 32); s.K = K;
   s.rows_out = M; s.rows_in = M; s.row_mul = 1; s.row_add = 0;
   return s;
+}
+GemmSeg seg_plain(const bf16_t* a_hi, const bf16_t* a_lo, int64_t lda, const Planes& w, int64_t wcol, int K, int M) {   // bf16 planes (backward pass)
+  Act a; a.p16 = const_cast<bf16_t*>(a_hi); a.lo16 = const_cast<bf16_t*>(a_lo);
+  return seg_plain(a, lda, w, wcol, K, M);
 }
 
 // y = x W^T (+ LoRA: [x | u] [W | B]^T with u = (alpha / r) x A^T) with the given epilogue
 int linear_with_lora(awt_encoder* e, bf16_t* const u[2], bf16_t* const in[2], int64_t ld_in, const Linear& lin, const LoraGroup& lg,
                      int M, GemmEpilogue epi, GemmOut out, hipStream_t s) {
-  const int terms = e->cfg.mfma_terms;
+  const int terms = e->prec;
+  const Act ain = make_act(in[0], in[1], (size_t)M * ld_in, terms);
   GemmSeg segs[2];
   int nseg = 1;
-  segs[0] = seg_plain(in[0], in[1], ld_in, lin.w, 0, lin.K, M);
+  segs[0] = seg_plain(ain, ld_in, lin.w, 0, lin.K, M);
   if (lg.active) {
-    GemmSeg us = seg_plain(in[0], in[1], ld_in, lg.a, 0, lin.K, M);
+    GemmSeg us = seg_plain(ain, ld_in, lg.a, 0, lin.K, M);
+    const Act au = make_act(u[0], u[1], (size_t)M * 128, terms);
     GemmOut uo{};
-    uo.hi = u[0]; uo.lo = u[1]; uo.ldo = lg.kp; uo.n_valid = lg.kp;
+    set_out(uo, au); uo.ldo = lg.kp; uo.n_valid = lg.kp;
     uo.scale = e->cfg.lora_alpha / (float)e->cfg.lora_rank;
     int rc = launch_gemm(e->ctx, M, 128, &us, 1, terms, EPI_BF16, uo, s); if (rc) return rc;
-    segs[1] = seg_plain(u[0], u[1], lg.kp, lg.b, 0, lg.kp, M);
+    segs[1] = seg_plain(au, lg.kp, lg.b, 0, lg.kp, M);
     nseg = 2;
   }
   out.bias = lin.bias;
@@ -332,18 +359,19 @@ TrainWs carve_train(const awt_encoder* e, char* base, int B) {
 // conv stem (K5-K7): mel [Bc, n_mels, T] -> residual stream x [Bc * S, d] fp32
 int conv_stem(awt_encoder* e, const float* mel, int Bc, bf16_t* const a1[2], bf16_t* const h1[2], float* x, hipStream_t s) {
   const awt_encoder_cfg& c = e->cfg;
-  const int S = c.n_ctx, T = 2 * S, d = c.d_model, terms = c.mfma_terms;
+  const int S = c.n_ctx, T = 2 * S, d = c.d_model, terms = e->prec;
   const int M = Bc * S, Mt = Bc * T;
   const int k1 = conv1_k(c.n_mels);
-  int rc = launch_im2col_conv1(e->ctx, mel, Bc, c.n_mels, T, k1, a1[0], a1[1], s); if (rc) return rc;
+  const Act aa1 = make_act(a1[0], a1[1], (size_t)Mt * k1, terms), ah1 = make_act(h1[0], h1[1], (size_t)Mt * d, terms);
+  int rc = launch_im2col_conv1(e->ctx, mel, Bc, c.n_mels, T, k1, aa1, terms, s); if (rc) return rc;
   {
-    GemmSeg sg = seg_plain(a1[0], a1[1], k1, e->conv1.w, 0, k1, Mt);
-    GemmOut o{}; o.hi = h1[0]; o.lo = h1[1]; o.ldo = d; o.bias = e->conv1.bias; o.n_valid = d;
+    GemmSeg sg = seg_plain(aa1, k1, e->conv1.w, 0, k1, Mt);
+    GemmOut o{}; set_out(o, ah1); o.ldo = d; o.bias = e->conv1.bias; o.n_valid = d;
     rc = launch_gemm(e->ctx, Mt, d, &sg, 1, terms, EPI_BF16_GELU, o, s); if (rc) return rc;
   }
   GemmSeg sg[3];
   for (int dt = 0; dt < 3; ++dt) {
-    sg[dt] = seg_plain(h1[0], h1[1], d, e->conv2.w, (int64_t)dt * d, d, M);
+    sg[dt] = seg_plain(ah1, d, e->conv2.w, (int64_t)dt * d, d, M);
     sg[dt].rows_out = S; sg[dt].rows_in = T; sg[dt].row_mul = 2; sg[dt].row_add = dt - 1;
   }
   GemmOut o{}; o.f32 = x; o.ldo = d; o.bias = e->conv2.bias; o.n_valid = d; o.pos = e->pos; o.rows_pos = S;
@@ -353,25 +381,32 @@ int conv_stem(awt_encoder* e, const float* mel, int Bc, bf16_t* const a1[2], bf1
 // one transformer layer (K8-K13) on the given buffers; `save` also keeps the MLP pre-activation and the softmax statistics
 int encoder_layer(awt_encoder* e, Layer& L, const LayerBufs& b, int Bc, bool save, hipStream_t s) {
   const awt_encoder_cfg& c = e->cfg;
-  const int S = c.n_ctx, d = c.d_model, f = c.ffn_dim, H = c.n_heads, terms = c.mfma_terms;
+  const int S = c.n_ctx, d = c.d_model, f = c.ffn_dim, H = c.n_heads, terms = e->prec;
   const int M = Bc * S;
   const int64_t plane = (int64_t)M * d;
-  int rc = launch_layernorm(e->ctx, b.x_in, L.ln1_g, L.ln1_b, M, d, 1e-5f, nullptr, b.ln1[0], b.ln1[1], s); if (rc) return rc;
+  const Act aqkv = make_act(b.qkv[0], b.qkv[1], 3 * (size_t)plane, terms), aatt = make_act(b.att[0], b.att[1], (size_t)plane, terms);
+  int rc = launch_layernorm(e->ctx, b.x_in, L.ln1_g, L.ln1_b, M, d, 1e-5f, nullptr, make_act(b.ln1[0], b.ln1[1], (size_t)plane, terms), terms, s); if (rc) return rc;
   {
-    GemmOut o{}; o.hi = b.qkv[0]; o.lo = b.qkv[1]; o.scale = 0.125f * 1.4426950408889634f;   // head_dim^-1/2 and log2(e): see attention.hip
+    GemmOut o{}; set_out(o, aqkv); o.scale = 0.125f * 1.4426950408889634f;   // head_dim^-1/2 and log2(e): see attention.hip
     o.S = S; o.H = H; o.plane_stride = plane;
     rc = linear_with_lora(e, b.u, b.ln1, d, L.qkv, L.lq, M, EPI_QKV, o, s); if (rc) return rc;
   }
-  rc = launch_attention(e->ctx, b.qkv[0], b.qkv[1], b.qkv[0] + plane, b.qkv[1] ? b.qkv[1] + plane : nullptr, b.qkv[0] + 2 * plane,
-                        b.qkv[1] ? b.qkv[1] + 2 * plane : nullptr, b.att[0], b.att[1], nullptr, save ? b.lse : nullptr, Bc, H, S, terms, s);
+  if (terms == PREC_F16F8) {
+    const Act ak = act_offset(aqkv, plane), av = act_offset(aqkv, 2 * plane);
+    rc = launch_attention_f16f8(e->ctx, F8Planes{aqkv.p16, aqkv.hi8, aqkv.lo8}, F8Planes{ak.p16, ak.hi8, ak.lo8}, F8Planes{av.p16, av.hi8, av.lo8},
+                                F8Planes{aatt.p16, aatt.hi8, aatt.lo8}, nullptr, save ? b.lse : nullptr, Bc, H, S, s);
+  } else {
+    rc = launch_attention(e->ctx, b.qkv[0], b.qkv[1], b.qkv[0] + plane, b.qkv[1] ? b.qkv[1] + plane : nullptr, b.qkv[0] + 2 * plane,
+                          b.qkv[1] ? b.qkv[1] + 2 * plane : nullptr, b.att[0], b.att[1], nullptr, save ? b.lse : nullptr, Bc, H, S, terms, s);
+  }
   if (rc) return rc;
   {
     GemmOut o{}; o.f32 = b.x_mid; o.resid = b.x_in; o.ldo = d;
     rc = linear_with_lora(e, b.u, b.att, d, L.out, L.lo_, M, EPI_F32_RESID, o, s); if (rc) return rc;
   }
-  rc = launch_layernorm(e->ctx, b.x_mid, L.ln2_g, L.ln2_b, M, d, 1e-5f, nullptr, b.ln2[0], b.ln2[1], s); if (rc) return rc;
+  rc = launch_layernorm(e->ctx, b.x_mid, L.ln2_g, L.ln2_b, M, d, 1e-5f, nullptr, make_act(b.ln2[0], b.ln2[1], (size_t)plane, terms), terms, s); if (rc) return rc;
   {
-    GemmOut o{}; o.hi = b.ff[0]; o.lo = b.ff[1]; o.ldo = f; o.hi2 = b.pre[0]; o.lo2 = b.pre[1];
+    GemmOut o{}; set_out(o, make_act(b.ff[0], b.ff[1], (size_t)M * f, terms)); o.ldo = f; o.hi2 = b.pre[0]; o.lo2 = b.pre[1];
     rc = linear_with_lora(e, b.u, b.ln2, d, L.fc1, L.l1, M, save ? EPI_BF16_GELU_SAVE : EPI_BF16_GELU, o, s); if (rc) return rc;
   }
   GemmOut o{}; o.f32 = b.x_out; o.resid = b.x_mid; o.ldo = d;
@@ -394,7 +429,7 @@ int forward_chunk(awt_encoder* e, const float* mel, int Bc, float* hidden, char*
     b.ff[p] = on ? w.ff[p] : nullptr; b.u[p] = on ? w.u[p] : nullptr; b.pre[p] = nullptr;
   }
   for (int li = 0; li < c.n_layers; ++li) { rc = encoder_layer(e, e->layers[li], b, Bc, false, s); if (rc) return rc; }
-  return launch_layernorm(e->ctx, w.x, e->lnf_g, e->lnf_b, M, d, 1e-5f, hidden, nullptr, nullptr, s);
+  return launch_layernorm(e->ctx, w.x, e->lnf_g, e->lnf_b, M, d, 1e-5f, hidden, Act{}, e->prec, s);
 }
 
 bool parse_layer(const char* name, int* idx, const char** rest) {
@@ -435,7 +470,10 @@ extern "C" int awt_encoder_create(awt_ctx* c, const awt_encoder_cfg* cfg, awt_en
   AWT_REQUIRE(cfg->ffn_dim > 0 && cfg->ffn_dim % 128 == 0, AWT_ERR_INVALID, "encoder_create: ffn_dim must be a multiple of 128");
   AWT_REQUIRE(cfg->n_mels > 0 && cfg->n_mels % 8 == 0 && cfg->n_mels <= 128, AWT_ERR_INVALID, "encoder_create: n_mels must be a multiple of 8, <= 128");
   AWT_REQUIRE(cfg->n_layers > 0 && cfg->n_ctx > 0, AWT_ERR_INVALID, "encoder_create: n_layers and n_ctx must be positive");
-  AWT_REQUIRE(cfg->mfma_terms == 1 || cfg->mfma_terms == 3, AWT_ERR_INVALID, "encoder_create: mfma_terms must be 1 or 3");
+  AWT_REQUIRE(cfg->mfma_terms == PREC_BF16 || cfg->mfma_terms == PREC_BF16X3 || cfg->mfma_terms == PREC_F16X3 || cfg->mfma_terms == PREC_F16F8, AWT_ERR_INVALID,
+              "encoder_create: mfma_terms must be 1 (bf16), 3 (bf16x3), 4 (fp16x3) or 5 (f16f8)");
+  AWT_REQUIRE(!cfg->training || cfg->mfma_terms == PREC_BF16 || cfg->mfma_terms == PREC_BF16X3, AWT_ERR_INVALID,
+              "encoder_create: training keeps its activations as bf16 planes: mfma_terms must be 1 or 3 (gradients do not fit fp16's range unscaled)");
   AWT_REQUIRE(cfg->backward_terms == 0 || cfg->backward_terms == cfg->mfma_terms || (cfg->backward_terms == 1 && cfg->mfma_terms == 3), AWT_ERR_INVALID,
               "encoder_create: backward_terms must be 0 (= mfma_terms), mfma_terms, or 1");
   AWT_REQUIRE(cfg->lora_rank >= 0 && cfg->lora_rank <= 32, AWT_ERR_INVALID, "encoder_create: lora_rank must be in 0..32");
@@ -443,7 +481,7 @@ extern "C" int awt_encoder_create(awt_ctx* c, const awt_encoder_cfg* cfg, awt_en
   AWT_REQUIRE(!cfg->training || (cfg->lora_rank > 0 && !(cfg->lora_targets & (AWT_LORA_OUT | AWT_LORA_FC1 | AWT_LORA_FC2))), AWT_ERR_INVALID,
               "encoder_create: training mode needs adapters, and supports them on q_proj / k_proj / v_proj only");
   awt_encoder* e = new awt_encoder();
-  e->ctx = c; e->cfg = *cfg; e->planes = cfg->mfma_terms == 3 ? 2 : 1;
+  e->ctx = c; e->cfg = *cfg; e->prec = cfg->mfma_terms; e->planes = cfg->mfma_terms == PREC_BF16 ? 1 : 2;
   e->chunk = cfg->chunk_clips > 0 ? cfg->chunk_clips : 64;
   const int d = cfg->d_model, f = cfg->ffn_dim;
   int rc = alloc_linear(e, &e->conv1, d, conv1_k(cfg->n_mels));
@@ -491,7 +529,7 @@ extern "C" int awt_encoder_set_weight(awt_encoder* e, const char* name, const fl
   const int d = c.d_model, f = c.ffn_dim, r = c.lora_rank;
   int rc = AWT_ERR_INVALID;
   auto pack = [&](const Planes& pl, int N, int C, int taps, int row_off, int col_off) {
-    return launch_pack_weight(e->ctx, data, N, C, taps, pl.ld, row_off, col_off, 1.0f, pl.hi, pl.lo, s);
+    return launch_pack_weight(e->ctx, data, N, C, taps, pl.ld, row_off, col_off, 1.0f, pl.hi, pl.lo, pl.x8, e->prec, s);
   };
   std::string nm(name);
   if (nm == "conv1.weight") { rc = check_shape(name, shape, rank, {d, c.n_mels, 3}); if (!rc) rc = pack(e->conv1.w, d, c.n_mels, 3, 0, 0); }
@@ -637,18 +675,18 @@ extern "C" int awt_op_linear(awt_ctx* c, const float* x, const float* w, const f
   bf16_t* xl = (bf16_t*)base;                 base += align_up((size_t)M * K * 2);
   bf16_t* wh = (bf16_t*)base;                 base += align_up((size_t)N * K * 2);
   bf16_t* wl = (bf16_t*)base;
-  int rc = launch_split_f32(c, x, (int64_t)M * K, 1.0f, xh, xl, s); if (rc) return rc;
-  rc = launch_pack_weight(c, w, N, K, 1, K, 0, 0, 1.0f, wh, wl, s); if (rc) return rc;     // fragment-major
-  GemmSeg sg{};
-  sg.a_hi = xh; sg.a_lo = xl; sg.lda = K; sg.w_hi = wh; sg.w_lo = wl; sg.w_ksteps = K / 32; sg.w_k0 = 0; sg.K = K;
-  sg.rows_out = M; sg.rows_in = M; sg.row_mul = 1; sg.row_add = 0;
+  const Act ax = make_act(xh, xl, (size_t)M * K, terms);
+  int rc = launch_split_planes(c, x, (int64_t)M * K, 1.0f, terms, kF8Act, xh, xl, ax.hi8, ax.lo8, s); if (rc) return rc;
+  rc = launch_pack_weight(c, w, N, K, 1, K, 0, 0, 1.0f, wh, wl, (uint8_t*)wl + (size_t)N * K, terms, s); if (rc) return rc;     // fragment-major
+  Planes pw; pw.hi = wh; pw.lo = wl; pw.x8 = (uint8_t*)wl + (size_t)N * K; pw.rows = N; pw.ld = K;
+  GemmSeg sg = seg_plain(ax, K, pw, 0, K, M);
   GemmOut o{}; o.f32 = y; o.ldo = N; o.bias = bias; o.n_valid = N;
   return launch_gemm(c, M, N, &sg, 1, terms, EPI_F32, o, s);
 }
 
 extern "C" int awt_op_layernorm(awt_ctx* c, const float* x, const float* gamma, const float* beta, float* y, int M, int d,
                                 float eps, void* stream) {
-  return launch_layernorm(c, x, gamma, beta, M, d, eps, y, nullptr, nullptr, (hipStream_t)stream);
+  return launch_layernorm(c, x, gamma, beta, M, d, eps, y, Act{}, PREC_BF16X3, (hipStream_t)stream);
 }
 
 extern "C" size_t awt_op_attention_workspace_bytes(int B, int H, int S) { return 6 * align_up((size_t)B * H * S * 64 * 2); }
@@ -704,7 +742,7 @@ extern "C" int awt_encoder_forward_train(awt_encoder* e, const float* mel, int B
   TrainWs w = carve_train(e, (char*)saved, B);
   rc = conv_stem(e, mel, B, w.a1, w.h1, w.layer[0].x_in, s); if (rc) return rc;
   for (int li = 0; li < e->cfg.n_layers; ++li) { rc = encoder_layer(e, e->layers[li], w.layer[li], B, true, s); if (rc) return rc; }
-  return launch_layernorm(e->ctx, w.x_final, e->lnf_g, e->lnf_b, B * e->cfg.n_ctx, e->cfg.d_model, 1e-5f, hidden, nullptr, nullptr, s);
+  return launch_layernorm(e->ctx, w.x_final, e->lnf_g, e->lnf_b, B * e->cfg.n_ctx, e->cfg.d_model, 1e-5f, hidden, Act{}, e->prec, s);
 }
 
 extern "C" int awt_encoder_set_comm(awt_encoder* e, awt_comm* m, int groups) {

@@ -131,6 +131,39 @@ __host__ __device__ __forceinline__ int64_t w_frag_index(int n, int k, int kstep
   return (((int64_t)nt * ksteps + ks) * 64 + (kq * 16 + r)) * 8 + j;
 }
 
+// f16f8 weights: the fp16 plane in v_mfma_f32_32x32x16_f16 B-fragment order (one 1 KB block per 32-row n-tile and 16-deep
+// k-step: lane 32 h + r holds W[32 nt + r][16 ks + 8 h + 0..7]) and the two e4m3 planes in the operand order of
+// v_mfma_scale_f32_32x32x64_f8f6f4 (one 2 KB block per n-tile and 64-deep K-tile: lane 32 h + r holds the 32 bytes
+// W[32 nt + r][64 kt + 32 h + 0..31]).  Rows are padded to a multiple of 32, K to a multiple of 64.
+__host__ __device__ __forceinline__ int64_t w16f8_index(int n, int k, int ksteps16) {
+  const int nt = n >> 5, r = n & 31, ks = k >> 4, h = (k & 15) >> 3, j = k & 7;
+  return (((int64_t)nt * ksteps16 + ks) * 64 + (h * 32 + r)) * 8 + j;
+}
+__host__ __device__ __forceinline__ int64_t w8_index(int n, int k, int ktiles64) {
+  const int nt = n >> 5, r = n & 31, kt = k >> 6, h = (k & 63) >> 5, b = k & 31;
+  return (((int64_t)nt * ktiles64 + kt) * 64 + (h * 32 + r)) * 32 + b;
+}
+
+// An activation matrix as MFMA operand planes: p16 (bf16 or fp16) + lo16 (split modes) or + hi8 / lo8 (f16f8)
+struct Act { bf16_t* p16 = nullptr; bf16_t* lo16 = nullptr; uint8_t* hi8 = nullptr; uint8_t* lo8 = nullptr; };
+// four consecutive elements at element offset `off` (a multiple of 4) in the planes of precision PREC; S = e4m3 exponent
+template <int PREC, int S = kF8Act>
+__device__ __forceinline__ void store_act4(const Act& o, int64_t off, const float (&v)[4]) {
+  if constexpr (PREC == PREC_F16F8) {
+    uint2 h16; unsigned hi8, lo8;
+    f16f8x4<S>(v, h16, hi8, lo8);
+    *reinterpret_cast<uint2*>(o.p16 + off) = h16;
+    *reinterpret_cast<unsigned*>(o.hi8 + off) = hi8;
+    *reinterpret_cast<unsigned*>(o.lo8 + off) = lo8;
+  } else {
+    bf16_t h[4], l[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) split16<PREC == PREC_F16X3>(v[t], h[t], l[t]);
+    *reinterpret_cast<uint2*>(o.p16 + off) = make_uint2(pack2(h[0], h[1]), pack2(h[2], h[3]));
+    if (o.lo16) *reinterpret_cast<uint2*>(o.lo16 + off) = make_uint2(pack2(l[0], l[1]), pack2(l[2], l[3]));
+  }
+}
+
 // ---------------------------------------------------------------- host-side error plumbing
 void awt_set_error(const std::string& msg);
 int awt_fail(int code, const std::string& msg);
@@ -189,6 +222,9 @@ struct GemmSeg {
   // weights in FRAGMENT-MAJOR order (w_frag_index below): element (n, k) of a matrix with `w_ksteps` = K_total / 32
   // k-steps; the segment starts at k-step `w_k0` of that matrix
   const bf16_t* w_hi; const bf16_t* w_lo; int w_ksteps, w_k0;
+  // PREC_F16F8: a_hi / w_hi are the fp16 planes, a_lo / w_lo are unused, and these are the e4m3 planes (activations row-major
+  // with the same lda, weights in w8_index order; w_ksteps / w_k0 still count 32-deep steps of the matrix / of the segment start)
+  const uint8_t* a8; const uint8_t* al8; const uint8_t* w8; const uint8_t* wl8;
   int K;                                                 // multiple of the kernel's BK
   // source row of output row m:  (m / rows_out) * rows_in + (m % rows_out) * row_mul + row_add ; rows outside
   // [0, rows_in) of their group read as zeros (the conv stem's padding).  Plain GEMM: rows_out = rows_in = M.
@@ -209,6 +245,7 @@ enum GemmEpilogue {
 struct GemmOut {
   float* f32; const float* resid; int64_t ldo;
   bf16_t* hi; bf16_t* lo;                 // lo may be null when terms == 1
+  uint8_t* hi8; uint8_t* lo8;             // PREC_F16F8: the e4m3 planes of the output (hi = its fp16 plane); same offsets as hi
   bf16_t* hi2; bf16_t* lo2;               // EPI_BF16_GELU_SAVE: pre-activation planes (same ldo)
   const bf16_t* pre_hi; const bf16_t* pre_lo;   // EPI_BF16_DGELU: saved pre-activation planes (same ldo)
   const float* bias;                      // [N] or null
@@ -219,11 +256,13 @@ struct GemmOut {
   int64_t plane_stride;
 };
 
-int launch_gemm(awt_ctx* c, int M, int N, const GemmSeg* segs, int nseg, int terms, GemmEpilogue epi, const GemmOut& out,
+// `prec`: PREC_* of the operands (and of plane outputs)
+int launch_gemm(awt_ctx* c, int M, int N, const GemmSeg* segs, int nseg, int prec, GemmEpilogue epi, const GemmOut& out,
                 hipStream_t s);
 
+// out_f32 (the final layer_norm) or operand planes of precision `prec`
 int launch_layernorm(awt_ctx* c, const float* x, const float* gamma, const float* beta, int M, int d, float eps,
-                     float* out_f32, bf16_t* out_hi, bf16_t* out_lo, hipStream_t s);
+                     float* out_f32, const Act& out, int prec, hipStream_t s);
 // q, k, v planes: bf16 [B, H, S, 64] (lo may be null for terms == 1); o: bf16 [B*S, H*64] hi/lo
 int launch_attention(awt_ctx* c, const bf16_t* q_hi, const bf16_t* q_lo, const bf16_t* k_hi, const bf16_t* k_lo,
                      const bf16_t* v_hi, const bf16_t* v_lo, bf16_t* o_hi, bf16_t* o_lo, float* o_f32, float* lse, int B, int H,
@@ -238,10 +277,12 @@ int launch_attention_f16f8(awt_ctx* c, const F8Planes& q, const F8Planes& k, con
                            float* lse, int B, int H, int S, hipStream_t s);
 // weights: dst(row_off + n, col_off + k) = scale * src[n, c, dt], k = dt * C + c (taps = 1: plain [N, C]); dst is a
 // fragment-major matrix with ld / 32 k-steps (ld = its K, a multiple of 32; its row count a multiple of 16)
+// prec PREC_F16F8: hi = fp16 plane (w16f8_index order), lo = the hi8 plane, lo8 = the lo8 plane (w8_index order); else hi / lo in
+// w_frag_index order (bf16, or fp16 for PREC_F16X3) and lo8 unused
 int launch_pack_weight(awt_ctx* c, const float* src, int N, int C, int taps, int64_t ld, int row_off, int col_off, float scale,
-                       bf16_t* hi, bf16_t* lo, hipStream_t s);
+                       bf16_t* hi, bf16_t* lo, uint8_t* lo8, int prec, hipStream_t s);
 // conv1 im2col: mel f32 [B, C, T] -> A [B*T, K_dst] bf16 hi/lo, k = dt * C + c reads mel[b, c, t + dt - 1]
-int launch_im2col_conv1(awt_ctx* c, const float* mel, int B, int C, int T, int K_dst, bf16_t* hi, bf16_t* lo, hipStream_t s);
+int launch_im2col_conv1(awt_ctx* c, const float* mel, int B, int C, int T, int K_dst, const Act& out, int prec, hipStream_t s);
 
 int logmel_whisper_impl(awt_ctx* c, const void* pcm, int pcm_is_i16, int64_t pcm_stride, const int32_t* n_valid,
                         int max_valid, int B, int n_frames_out, int n_mels, float* out, void* workspace, size_t ws_bytes, hipStream_t s);

@@ -9,9 +9,10 @@ namespace {
 // Output is either fp32 (final layer_norm -> last_hidden_state) or bf16 hi (+ lo) planes for the next GEMM.
 constexpr int kLnMaxChunks = 5;  // float4 chunks per lane: d <= 64 * 4 * 5 = 1280 (Whisper large)
 
+template <int PREC>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, int M, int d, float eps,
-                                                        float* out_f32, bf16_t* out_hi, bf16_t* out_lo) {
+                                                        float* out_f32, Act out) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -49,15 +50,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     const float4 g = g4[c], bb = b4[c];
     float y[4] = {(v[i].x - mean) * rstd * g.x + bb.x, (v[i].y - mean) * rstd * g.y + bb.y,
                   (v[i].z - mean) * rstd * g.z + bb.z, (v[i].w - mean) * rstd * g.w + bb.w};
-    if (out_f32) {
-      reinterpret_cast<float4*>(out_f32 + (int64_t)row * d)[c] = make_float4(y[0], y[1], y[2], y[3]);
-    } else {
-      bf16_t hi[4], lo[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) split_bf16(y[j], hi[j], lo[j]);
-      reinterpret_cast<uint2*>(out_hi + (int64_t)row * d)[c] = make_uint2(pack2(hi[0], hi[1]), pack2(hi[2], hi[3]));
-      if (out_lo) reinterpret_cast<uint2*>(out_lo + (int64_t)row * d)[c] = make_uint2(pack2(lo[0], lo[1]), pack2(lo[2], lo[3]));
-    }
+    if (out_f32) reinterpret_cast<float4*>(out_f32 + (int64_t)row * d)[c] = make_float4(y[0], y[1], y[2], y[3]);
+    else store_act4<PREC>(out, (int64_t)row * d + 4 * c, y);
   }
 }
 
@@ -100,18 +94,27 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
 // rows; taps = 1 is a plain [N, C] linear weight), written in the fragment-major layout of w_frag_index().  Only the
 // N x (C * taps) region is written: destination buffers are zero-initialised at creation, which provides every padding
 // row / column.
+template <int PREC>
 __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ src, int N, int C, int taps, int64_t ld,
-                                                          int row_off, int col_off, float scale, bf16_t* hi, bf16_t* lo) {
+                                                          int row_off, int col_off, float scale, bf16_t* hi, bf16_t* lo, uint8_t* lo8) {
   const int K = C * taps;
   const int64_t total = (int64_t)N * K;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int n = (int)(i / K), k = (int)(i - (int64_t)n * K);
     const int dt = k / C, c = k - dt * C;
     const float v = src[((int64_t)n * C + c) * taps + dt] * scale;
-    bf16_t h, l; split_bf16(v, h, l);
-    const int64_t o = w_frag_index(row_off + n, col_off + k, (int)(ld >> 5));
-    hi[o] = h;
-    if (lo) lo[o] = l;
+    if constexpr (PREC == PREC_F16F8) {
+      const bf16_t h = f32_to_f16(v);
+      hi[w16f8_index(row_off + n, col_off + k, (int)(ld >> 4))] = h;
+      const int64_t o8 = w8_index(row_off + n, col_off + k, (int)(ld >> 6));
+      reinterpret_cast<uint8_t*>(lo)[o8] = (uint8_t)(fp8x4<kF8Wgt>(v, 0.f, 0.f, 0.f) & 0xFF);
+      lo8[o8] = (uint8_t)(fp8x4<kF8Wgt + kF8Lo>(v - f16_to_f32(h), 0.f, 0.f, 0.f) & 0xFF);
+    } else {
+      bf16_t h, l; split16<PREC == PREC_F16X3>(v, h, l);
+      const int64_t o = w_frag_index(row_off + n, col_off + k, (int)(ld >> 5));
+      hi[o] = h;
+      if (lo) lo[o] = l;
+    }
   }
 }
 
@@ -120,8 +123,8 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
 // the clip: Conv1d padding = 1, HF:modeling_whisper.py:566).  A 64-frame slab of the clip is staged in LDS with
 // reads coalesced along t; rows are written as whole 16-byte groups so each row is one contiguous K_dst * 2 B store.
 constexpr int kImTile = 64;
-__global__ __launch_bounds__(256) void im2col_conv1_kernel(const float* __restrict__ mel, int C, int T, int K_dst, bf16_t* hi,
-                                                           bf16_t* lo) {
+template <int PREC>
+__global__ __launch_bounds__(256) void im2col_conv1_kernel(const float* __restrict__ mel, int C, int T, int K_dst, Act out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* tile = reinterpret_cast<float*>(smem);   // [C][kImTile + 2], pitch kImTile + 3 (odd: conflict-free column reads)
   const int pitch = kImTile + 3;
@@ -140,15 +143,12 @@ __global__ __launch_bounds__(256) void im2col_conv1_kernel(const float* __restri
     const int t = t0 + tl;
     if (t >= T) continue;
     const int dt = g / cg, c0 = (g - dt * cg) * 8;
-    bf16_t h[8], l[8];
+    float v[2][4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float v = dt < 3 ? tile[(c0 + j) * pitch + tl + dt] : 0.f;
-      split_bf16(v, h[j], l[j]);
-    }
+    for (int j = 0; j < 8; ++j) v[j >> 2][j & 3] = dt < 3 ? tile[(c0 + j) * pitch + tl + dt] : 0.f;
     const int64_t off = ((int64_t)b * T + t) * K_dst + g * 8;
-    *reinterpret_cast<uint4*>(hi + off) = make_uint4(pack2(h[0], h[1]), pack2(h[2], h[3]), pack2(h[4], h[5]), pack2(h[6], h[7]));
-    if (lo) *reinterpret_cast<uint4*>(lo + off) = make_uint4(pack2(l[0], l[1]), pack2(l[2], l[3]), pack2(l[4], l[5]), pack2(l[6], l[7]));
+    store_act4<PREC>(out, off, v[0]);
+    store_act4<PREC>(out, off + 4, v[1]);
   }
 }
 
@@ -322,11 +322,15 @@ __global__ __launch_bounds__(256) void outer_reduce_final_kernel(const float* pa
 }  // namespace
 
 int launch_layernorm(awt_ctx* c, const float* x, const float* gamma, const float* beta, int M, int d, float eps,
-                     float* out_f32, bf16_t* out_hi, bf16_t* out_lo, hipStream_t s) {
-  AWT_REQUIRE(x && gamma && beta && (out_f32 || out_hi), AWT_ERR_INVALID, "layernorm: null argument");
+                     float* out_f32, const Act& out, int prec, hipStream_t s) {
+  AWT_REQUIRE(x && gamma && beta && (out_f32 || out.p16), AWT_ERR_INVALID, "layernorm: null argument");
+  AWT_REQUIRE(out_f32 || prec != PREC_F16F8 || (out.hi8 && out.lo8), AWT_ERR_INVALID, "layernorm: f16f8 output needs both e4m3 planes");
   AWT_REQUIRE(M > 0 && d > 0 && d % 4 == 0 && d <= 64 * 4 * kLnMaxChunks, AWT_ERR_INVALID, "layernorm: d must be a multiple of 4 and <= 1280");
   ProfScope prof(c, AWT_PROF_LAYERNORM, s, 0.0);
-  hipLaunchKernelGGL(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, gamma, beta, M, d, eps, out_f32, out_hi, out_lo);
+  const dim3 grid((M + 3) / 4), block(256);
+  if (prec == PREC_F16F8) hipLaunchKernelGGL(layernorm_kernel<PREC_F16F8>, grid, block, 0, s, x, gamma, beta, M, d, eps, out_f32, out);
+  else if (prec == PREC_F16X3) hipLaunchKernelGGL(layernorm_kernel<PREC_F16X3>, grid, block, 0, s, x, gamma, beta, M, d, eps, out_f32, out);
+  else hipLaunchKernelGGL(layernorm_kernel<PREC_BF16X3>, grid, block, 0, s, x, gamma, beta, M, d, eps, out_f32, out);
   AWT_HIP_CHECK(hipGetLastError());
   return AWT_OK;
 }
@@ -359,20 +363,27 @@ int launch_split_planes(awt_ctx* c, const float* x, int64_t n, float scale, int 
 }
 
 int launch_pack_weight(awt_ctx* c, const float* src, int N, int C, int taps, int64_t ld, int row_off, int col_off, float scale,
-                       bf16_t* hi, bf16_t* lo, hipStream_t s) {
+                       bf16_t* hi, bf16_t* lo, uint8_t* lo8, int prec, hipStream_t s) {
   AWT_REQUIRE(src && hi && N > 0 && C > 0 && taps > 0 && ld >= col_off + (int64_t)C * taps && ld % 32 == 0, AWT_ERR_INVALID, "pack_weight: bad shape");
+  AWT_REQUIRE(prec != PREC_F16F8 || (lo && lo8 && ld % 64 == 0), AWT_ERR_INVALID, "pack_weight: f16f8 needs both e4m3 planes and K a multiple of 64");
   const int64_t total = (int64_t)N * C * taps;
   int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
-  hipLaunchKernelGGL(pack_weight_kernel, dim3(grid), dim3(256), 0, s, src, N, C, taps, ld, row_off, col_off, scale, hi, lo);
+  if (prec == PREC_F16F8) hipLaunchKernelGGL(pack_weight_kernel<PREC_F16F8>, dim3(grid), dim3(256), 0, s, src, N, C, taps, ld, row_off, col_off, scale, hi, lo, lo8);
+  else if (prec == PREC_F16X3) hipLaunchKernelGGL(pack_weight_kernel<PREC_F16X3>, dim3(grid), dim3(256), 0, s, src, N, C, taps, ld, row_off, col_off, scale, hi, lo, lo8);
+  else hipLaunchKernelGGL(pack_weight_kernel<PREC_BF16X3>, dim3(grid), dim3(256), 0, s, src, N, C, taps, ld, row_off, col_off, scale, hi, lo, lo8);
   AWT_HIP_CHECK(hipGetLastError());
   return AWT_OK;
 }
 
-int launch_im2col_conv1(awt_ctx* c, const float* mel, int B, int C, int T, int K_dst, bf16_t* hi, bf16_t* lo, hipStream_t s) {
-  AWT_REQUIRE(mel && hi && B > 0 && C > 0 && C % 8 == 0 && T > 0 && K_dst % 8 == 0 && K_dst >= 3 * C, AWT_ERR_INVALID, "im2col: bad shape");
+int launch_im2col_conv1(awt_ctx* c, const float* mel, int B, int C, int T, int K_dst, const Act& out, int prec, hipStream_t s) {
+  AWT_REQUIRE(mel && out.p16 && B > 0 && C > 0 && C % 8 == 0 && T > 0 && K_dst % 8 == 0 && K_dst >= 3 * C, AWT_ERR_INVALID, "im2col: bad shape");
+  AWT_REQUIRE(prec != PREC_F16F8 || (out.hi8 && out.lo8), AWT_ERR_INVALID, "im2col: f16f8 output needs both e4m3 planes");
   ProfScope prof(c, AWT_PROF_OTHER, s, 0.0);
   const size_t lds = (size_t)C * (kImTile + 3) * sizeof(float);
-  hipLaunchKernelGGL(im2col_conv1_kernel, dim3((T + kImTile - 1) / kImTile, B), dim3(256), lds, s, mel, C, T, K_dst, hi, lo);
+  const dim3 grid((T + kImTile - 1) / kImTile, B), block(256);
+  if (prec == PREC_F16F8) hipLaunchKernelGGL(im2col_conv1_kernel<PREC_F16F8>, grid, block, lds, s, mel, C, T, K_dst, out);
+  else if (prec == PREC_F16X3) hipLaunchKernelGGL(im2col_conv1_kernel<PREC_F16X3>, grid, block, lds, s, mel, C, T, K_dst, out);
+  else hipLaunchKernelGGL(im2col_conv1_kernel<PREC_BF16X3>, grid, block, lds, s, mel, C, T, K_dst, out);
   AWT_HIP_CHECK(hipGetLastError());
   return AWT_OK;
 }

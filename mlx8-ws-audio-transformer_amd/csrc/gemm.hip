@@ -30,6 +30,7 @@
 namespace {
 
 constexpr int kMaxSeg = 3;
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
 
 struct GemmArgs {
   int M, N, nseg, tiles_m, tiles_n;
@@ -157,7 +158,8 @@ __device__ __forceinline__ float4 load_side4(const GemmOut& o, int m, int n, int
   return r;
 }
 
-template <int EPI>
+// OP = precision of plane outputs (PREC_BF16X3: bf16 hi / lo; PREC_F16X3: fp16 hi / lo; PREC_F16F8: fp16 + two e4m3 planes)
+template <int EPI, int OP>
 __device__ __forceinline__ void store_out4(const GemmOut& o, int m, int n, float4 acc, float4 side, int M) {
 #ifdef AWT_DIAG_NO_STORE   // timing-only: epilogue arithmetic kept alive, nothing written
   if (acc.x != 123.456f) { asm volatile("" ::"v"(acc.y), "v"(side.x)); return; }
@@ -181,9 +183,11 @@ __device__ __forceinline__ void store_out4(const GemmOut& o, int m, int n, float
     *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
   } else {
     int64_t off;
+    float f8s = pow2f(kF8Act);          // PREC_F16F8: scale of the e4m3 planes by operand role
     if (EPI == EPI_QKV) {
       const int d = o.H * 64;
       const int which = n / d, within = n - which * d;
+      f8s = which == 0 ? pow2f(kF8Q) : pow2f(kF8KV);
       const int h = within >> 6, e = within & 63;
       const int b = m / o.S, s = m - b * o.S;
       if (which == 0) { v[0] *= o.scale; v[1] *= o.scale; v[2] *= o.scale; v[3] *= o.scale; }
@@ -208,15 +212,24 @@ __device__ __forceinline__ void store_out4(const GemmOut& o, int m, int n, float
         for (int t = 0; t < 4; ++t) v[t] = (EPI == EPI_BF16_GELU || EPI == EPI_BF16_GELU_SAVE) ? gelu_erf(v[t]) : v[t] * o.scale;
       }
     }
-    bf16_t hi[4], lo[4];
+    if constexpr (OP == PREC_F16F8) {
+      bf16_t h[4]; float l[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) split_bf16(v[t], hi[t], lo[t]);
-    *reinterpret_cast<uint2*>(o.hi + off) = make_uint2(pack2(hi[0], hi[1]), pack2(hi[2], hi[3]));
-    if (o.lo) *reinterpret_cast<uint2*>(o.lo + off) = make_uint2(pack2(lo[0], lo[1]), pack2(lo[2], lo[3]));
+      for (int t = 0; t < 4; ++t) { h[t] = f32_to_f16(v[t]); l[t] = (v[t] - f16_to_f32(h[t])) * (f8s * pow2f(kF8Lo)); }
+      *reinterpret_cast<uint2*>(o.hi + off) = make_uint2(pack2(h[0], h[1]), pack2(h[2], h[3]));
+      *reinterpret_cast<unsigned*>(o.hi8 + off) = fp8x4<0>(v[0] * f8s, v[1] * f8s, v[2] * f8s, v[3] * f8s);
+      *reinterpret_cast<unsigned*>(o.lo8 + off) = fp8x4<0>(l[0], l[1], l[2], l[3]);
+    } else {
+      bf16_t hi[4], lo[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) split16<OP == PREC_F16X3>(v[t], hi[t], lo[t]);
+      *reinterpret_cast<uint2*>(o.hi + off) = make_uint2(pack2(hi[0], hi[1]), pack2(hi[2], hi[3]));
+      if (o.lo) *reinterpret_cast<uint2*>(o.lo + off) = make_uint2(pack2(lo[0], lo[1]), pack2(lo[2], lo[3]));
+    }
   }
 }
 
-template <int TERMS, int BK, int EPI, class CFG>
+template <int TERMS, int BK, int EPI, class CFG, bool F16>
 __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, 2) void gemm_kernel(GemmArgs g) {
   using T = Tile<TERMS, BK, CFG>;
   using ST = Stager<TERMS, BK, CFG>;
@@ -307,10 +320,10 @@ __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, 2) void gemm_kernel(GemmArg
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       if (TERMS == 3) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s & 1], bl[ks][j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[s & 1], bh[ks][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = mfma16<F16>(ah[s & 1], bl[ks][j], acc[i][j]);
+        acc[i][j] = mfma16<F16>(al[s & 1], bh[ks][j], acc[i][j]);
       }
-      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s & 1], bh[ks][j], acc[i][j], 0, 0, 0);
+      acc[i][j] = mfma16<F16>(ah[s & 1], bh[ks][j], acc[i][j]);
     }
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -358,7 +371,7 @@ __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, 2) void gemm_kernel(GemmArg
     for (int it = 0; it < 4; ++it) {
       const int rl = fq + 4 * it;
       const float4 v = *reinterpret_cast<const float4*>(patch + rl * PITCH + frow * 4);
-      store_out4<EPI>(g.out, em0 + i * 16 + rl, en, v, side[it], g.M);
+      store_out4<EPI, F16 ? PREC_F16X3 : PREC_BF16X3>(g.out, em0 + i * 16 + rl, en, v, side[it], g.M);
     }
 #pragma unroll
     for (int it = 0; it < 4; ++it) side[it] = side_next[it];
@@ -367,20 +380,290 @@ __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, 2) void gemm_kernel(GemmArg
   }
 }
 
+
+// ================================================================================================ PREC_F16F8
+// Same GEMM in the f16f8 operand format (common.h): per 64-deep K-tile and fragment pair
+//     a16 w16                 4 k-steps of v_mfma_f32_32x32x16_f16          (32 cycles each)
+//     a8 wl8 + al8 w8         2 x v_mfma_scale_f32_32x32x64_f8f6f4 (e4m3)   (64 cycles each)
+// = 256 matrix-pipe cycles where the split-bf16 kernel spends 384, with the same operand bytes (4 per element: fp16 + two
+// e4m3 planes) and ONE barrier per 64 of K instead of two.  Block tiles: 128 x 256 on 4 waves (1 x 4, wave tile 128 x 64 =
+// 4 x 2 MFMA tiles of 32 x 32) and 128 x 128 (2 x 2 waves of 64 x 64) for N not a multiple of 256 / small M; 32 KB of LDS per
+// stage (A16 16 KB | A8 8 KB | Al8 8 KB), two stages, two workgroups per CU.  Operand routes as in the kernel above: the
+// activation planes by 16-byte LDS-DMA into swizzled images, the weight fragments from their fragment-major copies straight
+// into registers -- here as a register RING: the registers of k-step ks are reloaded for the next K-tile right after
+// their last MFMA, a whole K-tile ahead of their next use, so the weights need 64 VGPRs, not 128.  Every global address is
+// a wave-uniform base (SGPR pair) plus a 32-bit per-lane offset.  The W loads are inline asm and every wait is counted by
+// hand (vmcnt retires in issue order): hipcc would wait vmcnt(0) at any use of an ordinary load while an LDS-DMA is in
+// flight (cdna_hip_programming.md "Projection GEMM at M = 256" item 4b).  The last K-tile prefetches itself again (results
+// unused) so that the loop body has no branches.
+struct CfgF8W4 { static constexpr int WM = 1, WN = 4, TM = 4, TN = 2; };     // 128 x 256
+struct CfgF8Sq { static constexpr int WM = 2, WN = 2, TM = 2, TN = 2; };     // 128 x 128
+
+template <int OFF>
+__device__ __forceinline__ bf16x8 gload16(unsigned voff, const void* sbase) {
+  bf16x8 v;
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(v) : "v"(voff), "s"(sbase), "n"(OFF));
+  return v;
+}
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ i32x8 cat8(bf16x8 lo, bf16x8 hi) {
+  return __builtin_shufflevector(__builtin_bit_cast(i32x4_t, lo), __builtin_bit_cast(i32x4_t, hi), 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <int EPI, class CFG, bool MULTI>
+__global__ __launch_bounds__(256, 2) void gemm_f8_kernel(GemmArgs g) {
+  constexpr int WM = CFG::WM, WN = CFG::WN, TM = CFG::TM, TN = CFG::TN;
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32, BK = 64;
+  static_assert(BM == 128 && WM * WN == 4, "128-row block tiles on four waves");
+  constexpr int PL16 = BM * BK * 2, PL8 = BM * BK, STAGE = PL16 + 2 * PL8;     // 16 + 8 + 8 KB
+  constexpr int IT16 = PL16 / 16 / 256, IT8 = PL8 / 16 / 256;                   // LDS-DMA pieces per thread: 4, 2 (+ 2)
+  constexpr int NDMA = IT16 + 2 * IT8;                                          // 8
+  constexpr int NW16 = 4 * TN, NW8 = 4 * TN;                                    // W loads per lane per K-tile: fp16 (4 k-steps x TN), e4m3 (2 planes x TN x 2)
+  constexpr unsigned kInvalid = 0xFFFFFFFFu;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tid = wave * 64 + lane;
+
+  // tile order: as gemm_kernel (XCD-contiguous runs, groups of GM row panels)
+  const int nwg = g.tiles_m * g.tiles_n;
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int qn = nwg >> 3, rn = nwg & 7;
+  const int tile = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + idx;
+  constexpr int GM = AWT_GEMM_GM;
+  int tm, tn;
+  {
+    const int grp = tile / (GM * g.tiles_n);
+    const int gm = min(GM, g.tiles_m - grp * GM);
+    const int within = tile - grp * GM * g.tiles_n;
+    tn = within / gm; tm = grp * GM + (within - tn * gm);
+  }
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int wr = wave / WN, wc = wave - wr * WN;
+  const int r32 = lane & 31, half = lane >> 5;
+
+  int ktiles = 0;
+  for (int s = 0; s < (MULTI ? g.nseg : 1); ++s) ktiles += g.seg[s].K / BK;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x16){};
+
+  // ---- operand streams: wave-uniform bases (SGPRs, advanced per K-tile) + 32-bit per-lane offsets (fixed per K-segment)
+  unsigned a16o[IT16], a8o[IT8];                   // byte offsets of the thread's DMA pieces inside the fp16 / e4m3 planes
+  const char *a16b, *a8b, *al8b;                   // plane bases + the current K-tile's column offset
+  const char *w16b[TN], *w8b[TN], *wl8b[TN];       // block of n-tile j at the current K-tile
+  const unsigned wl16 = lane * 16, wl32 = lane * 32;
+  int si = 0, kk = 0, nk = 0;
+  auto open_segment = [&](int seg) {
+    si = seg; kk = 0;
+    const GemmSeg& sg = g.seg[seg];
+    nk = sg.K / BK;
+#pragma unroll
+    for (int it = 0; it < IT16; ++it) {
+      const int p = it * 256 + tid, row = p >> 3, c = (p & 7) ^ ((row >> 1) & 7);
+      int m = m0 + row; m = m < g.M ? m : g.M - 1;
+      const int grp = m / sg.rows_out, r = m - grp * sg.rows_out;
+      const int sr = r * sg.row_mul + sg.row_add;
+      a16o[it] = (sr >= 0 && sr < sg.rows_in) ? (unsigned)((((int64_t)grp * sg.rows_in + sr) * sg.lda + c * 8) * 2) : kInvalid;
+    }
+#pragma unroll
+    for (int it = 0; it < IT8; ++it) {
+      const int p = it * 256 + tid, row = p >> 2, c = (p & 3) ^ ((row >> 2) & 3);
+      int m = m0 + row; m = m < g.M ? m : g.M - 1;
+      const int grp = m / sg.rows_out, r = m - grp * sg.rows_out;
+      const int sr = r * sg.row_mul + sg.row_add;
+      a8o[it] = (sr >= 0 && sr < sg.rows_in) ? (unsigned)(((int64_t)grp * sg.rows_in + sr) * sg.lda + c * 16) : kInvalid;
+    }
+    a16b = (const char*)sg.a_hi; a8b = (const char*)sg.a8; al8b = (const char*)sg.al8;
+    const int nt0 = (n0 >> 5) + wc * TN;
+    const int64_t w16_ts = (int64_t)sg.w_ksteps * 2 * 1024;          // bytes per 32-row n-tile of the fp16 plane: (K / 16) blocks of 1 KB
+    const int64_t w8_ts = (int64_t)(sg.w_ksteps / 2) * 2048;         // bytes per n-tile of an e4m3 plane: (K / 64) blocks of 2 KB
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      w16b[j] = (const char*)sg.w_hi + (nt0 + j) * w16_ts + (int64_t)sg.w_k0 * 2 * 1024;
+      w8b[j] = (const char*)sg.w8 + (nt0 + j) * w8_ts + (int64_t)(sg.w_k0 / 2) * 2048;
+      wl8b[j] = (const char*)sg.wl8 + (nt0 + j) * w8_ts + (int64_t)(sg.w_k0 / 2) * 2048;
+    }
+  };
+  // point the streams at the next K-tile (the last K-tile of the GEMM points at itself again)
+  auto advance = [&]() {
+    if (kk + 1 < nk) {
+      ++kk;
+      a16b += BK * 2; a8b += BK; al8b += BK;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) { w16b[j] += 4 * 1024; w8b[j] += 2048; wl8b[j] += 2048; }
+    } else if (MULTI && si + 1 < g.nseg) {
+      open_segment(si + 1);
+    }
+  };
+  // DMA piece OP (0 .. NDMA - 1) of the K-tile the streams point at
+  auto dma = [&](auto op_t, char* stage) {
+    constexpr int OP = decltype(op_t)::value;
+    if constexpr (OP < IT16) {
+      const unsigned o = a16o[OP];
+      glds16(o != kInvalid ? (const void*)(a16b + o) : (const void*)g.zeros, stage + (OP * 256 + wave * 64) * 16);
+    } else if constexpr (OP < IT16 + IT8) {
+      const unsigned o = a8o[OP - IT16];
+      glds16(o != kInvalid ? (const void*)(a8b + o) : (const void*)g.zeros, stage + PL16 + ((OP - IT16) * 256 + wave * 64) * 16);
+    } else {
+      const unsigned o = a8o[OP - IT16 - IT8];
+      glds16(o != kInvalid ? (const void*)(al8b + o) : (const void*)g.zeros, stage + PL16 + PL8 + ((OP - IT16 - IT8) * 256 + wave * 64) * 16);
+    }
+  };
+
+  bf16x8 w16[4][TN];              // fp16 B fragments of the K-tile's four k-steps
+  bf16x8 w8[TN][2], wl8[TN][2];   // e4m3 operands (32 bytes = two 16-byte halves)
+  auto load_w16 = [&](auto ks_t) {
+    constexpr int ks = decltype(ks_t)::value;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) w16[ks][j] = gload16<ks * 1024>(wl16, w16b[j]);
+  };
+  auto load_w8 = [&]() {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      w8[j][0] = gload16<0>(wl32, w8b[j]); w8[j][1] = gload16<16>(wl32, w8b[j]);
+      wl8[j][0] = gload16<0>(wl32, wl8b[j]); wl8[j][1] = gload16<16>(wl32, wl8b[j]);
+    }
+  };
+
+  // ---- prologue: K-tile 0 into stage 0 and into the W registers
+  open_segment(0);
+  [&]<int... O>(std::integer_sequence<int, O...>) { (dma(std::integral_constant<int, O>{}, smem), ...); }(std::make_integer_sequence<int, NDMA>{});
+  [&]<int... S>(std::integer_sequence<int, S...>) { (load_w16(std::integral_constant<int, S>{}), ...); }(std::make_integer_sequence<int, 4>{});
+  load_w8();
+  wait_vm<0>();
+  __builtin_amdgcn_s_barrier();
+
+  // A fragment offsets inside a stage: fp16 image row r, chunk (2 ks + half) ^ ((r >> 1) & 7); e4m3 images row r, chunks
+  // (2 half + c) ^ ((r >> 2) & 3).  Row tile i adds a multiple of 32 rows, which leaves both swizzle terms unchanged.
+  int a16off[4], a8off[2];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) a16off[ks] = (wr * TM * 32 + r32) * 128 + (((2 * ks + half) ^ ((r32 >> 1) & 7)) << 4);
+#pragma unroll
+  for (int c = 0; c < 2; ++c) a8off[c] = PL16 + (wr * TM * 32 + r32) * 64 + (((2 * half + c) ^ ((r32 >> 2) & 3)) << 4);
+
+  constexpr int DMA_PER_STEP = (NDMA + TM - 1) / TM;    // every DMA piece is issued during k-step 0, ahead of all W reloads
+  // One K-tile.  PF (compile time): prefetch K-tile kt + 1 (A by LDS-DMA into the other stage, W into the register ring).  The
+  // last K-tile is instantiated without any load: a load still in flight when the loop ends would land in registers the
+  // epilogue has already reused (the compiler cannot see that an inline-asm load completes later).
+  auto ktile = [&](auto pf_t, int kt) {
+    constexpr bool PF = decltype(pf_t)::value;
+    const char* cur = smem + (kt & 1) * STAGE;
+    char* nxt = smem + ((kt + 1) & 1) * STAGE;
+    if constexpr (PF) advance();        // from here on the streams point at K-tile kt + 1 (the W registers still hold K-tile kt)
+    // ---- fp16 part: k-step ks, row tile i: one 16-byte A fragment against the wave's TN weight fragments
+    bf16x8 af[2];
+    af[0] = *reinterpret_cast<const bf16x8*>(cur + a16off[0]);
+    [&]<int... S>(std::integer_sequence<int, S...>) {
+      ([&] {
+        constexpr int ks = S / TM, i = S % TM;
+        if constexpr (S + 1 < 4 * TM) af[(S + 1) & 1] = *reinterpret_cast<const bf16x8*>(cur + a16off[(S + 1) / TM] + ((S + 1) % TM) * 32 * 128);
+        if constexpr (PF && ks == 0) {
+          [&]<int... O>(std::integer_sequence<int, O...>) {
+            ([&] { constexpr int op = i * DMA_PER_STEP + O; if constexpr (op < NDMA) dma(std::integral_constant<int, op>{}, nxt); }(), ...);
+          }(std::make_integer_sequence<int, DMA_PER_STEP>{});
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = mfma32<true>(af[S & 1], w16[ks][j], acc[i][j]);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (PF && i == TM - 1) load_w16(std::integral_constant<int, ks>{});     // ring: this k-step's registers, for K-tile kt + 1
+      }(), ...);
+    }(std::make_integer_sequence<int, 4 * TM>{});
+    // ---- e4m3 part: its W registers were loaded a K-tile ago, behind this K-tile's NDMA + NW16 younger operations
+    if constexpr (PF) wait_vm<NDMA + NW16>(); else wait_vm<0>();
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const char* rowp = cur + i * 32 * 64;
+      const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(rowp + a8off[0]), x1 = *reinterpret_cast<const bf16x8*>(rowp + a8off[1]);
+      const bf16x8 y0 = *reinterpret_cast<const bf16x8*>(rowp + PL8 + a8off[0]), y1 = *reinterpret_cast<const bf16x8*>(rowp + PL8 + a8off[1]);
+      const i32x8 a8 = cat8(x0, x1), al8 = cat8(y0, y1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        acc[i][j] = mfma32_f8<e8m0(-kF8Act), e8m0(-kF8Wgt - kF8Lo)>(a8, cat8(wl8[j][0], wl8[j][1]), acc[i][j]);
+        acc[i][j] = mfma32_f8<e8m0(-kF8Act - kF8Lo), e8m0(-kF8Wgt)>(al8, cat8(w8[j][0], w8[j][1]), acc[i][j]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (PF) {
+      load_w8();
+      // the DMA pieces and the fp16 W fragments of K-tile kt + 1 are older than the NW8 e4m3 loads just issued
+      wait_vm<NW8>();
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+  for (int kt = 0; kt + 1 < ktiles; ++kt) ktile(std::true_type{}, kt);
+  ktile(std::false_type{}, ktiles - 1);
+
+  // ---- epilogue: each wave transposes one 32-row x 64-column strip at a time through a private LDS patch (32 x 32 C/D
+  // layout: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)) and writes whole 256-byte row segments.
+  static_assert(TN == 2, "epilogue strips are 64 columns wide");
+  constexpr int PITCH = 68;
+  float* patch = reinterpret_cast<float*>(smem) + wave * (32 * PITCH);      // 8704 B per wave
+  const int frow = lane & 15, fq = lane >> 4;
+  const int em0 = m0 + wr * TM * 32, en = n0 + wc * 64 + frow * 4;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) patch[((rr & 3) + 8 * (rr >> 2) + 4 * half) * PITCH + j * 32 + r32] = acc[i][j][rr];
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {       // two groups of four rows per lane: side inputs of a group are loaded together
+      float4 side[4];
+#pragma unroll
+      for (int it = 0; it < 4; ++it) side[it] = load_side4<EPI>(g.out, em0 + i * 32 + fq + 4 * (4 * h2 + it), en, g.M);
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int rl = fq + 4 * (4 * h2 + it);
+        const float4 v = *reinterpret_cast<const float4*>(patch + rl * PITCH + frow * 4);
+        store_out4<EPI, PREC_F16F8>(g.out, em0 + i * 32 + rl, en, v, side[it], g.M);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+}
+
+template <int EPI, class CFG>
+int launch_f8(GemmArgs a, hipStream_t s) {
+  constexpr int BM = CFG::WM * CFG::TM * 32, BN = CFG::WN * CFG::TN * 32;
+  constexpr int lds = 2 * (BM * 64 * 2 + 2 * BM * 64);     // two stages of A16 | A8 | Al8 = 64 KB (>= the epilogue patches)
+  a.tiles_m = (a.M + BM - 1) / BM;
+  a.tiles_n = (a.N + BN - 1) / BN;
+  a.group_n = 0;
+  if (a.nseg == 1) {
+    AWT_ONCE_PER_DEVICE(AWT_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_f8_kernel<EPI, CFG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)));
+    hipLaunchKernelGGL((gemm_f8_kernel<EPI, CFG, false>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
+  } else {
+    AWT_ONCE_PER_DEVICE(AWT_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_f8_kernel<EPI, CFG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)));
+    hipLaunchKernelGGL((gemm_f8_kernel<EPI, CFG, true>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
+  }
+  AWT_HIP_CHECK(hipGetLastError());
+  return AWT_OK;
+}
+
 int g_force_tile = 0;  // 0 = auto, 64 / 128 / 256 = forced (tuning and tests)
 // Tile order (see the kernel).  Measured on the encoder's shapes (tools/gemm_traffic_shapes.sh, profiles/r01_gemm_tile_order.txt):
 // column-tile groups of 3 cut the L2 -> fabric reads by 10 - 25 % but run 1.5 % slower end to end than groups of GM = 4 row
 // panels, so row-panel groups are the default; AWT_GEMM_GROUP_N=n selects column groups for experiments.
 int g_group_n = 0;
 
-template <int TERMS, int BK, int EPI, class CFG>
+template <int TERMS, int BK, int EPI, class CFG, bool F16 = false>
 int launch_one(GemmArgs a, hipStream_t s) {
   using T = Tile<TERMS, BK, CFG>;
-  AWT_ONCE_PER_DEVICE(AWT_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_kernel<TERMS, BK, EPI, CFG>, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES)));
+  AWT_ONCE_PER_DEVICE(AWT_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_kernel<TERMS, BK, EPI, CFG, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES)));
   a.tiles_m = (a.M + T::BM - 1) / T::BM;
   a.tiles_n = (a.N + T::BN - 1) / T::BN;
   a.group_n = g_group_n;
-  hipLaunchKernelGGL((gemm_kernel<TERMS, BK, EPI, CFG>), dim3(a.tiles_m * a.tiles_n), dim3(T::THREADS), T::LDS_BYTES, s, a);
+  hipLaunchKernelGGL((gemm_kernel<TERMS, BK, EPI, CFG, F16>), dim3(a.tiles_m * a.tiles_n), dim3(T::THREADS), T::LDS_BYTES, s, a);
   AWT_HIP_CHECK(hipGetLastError());
   return AWT_OK;
 }
@@ -392,7 +675,27 @@ int launch_one(GemmArgs a, hipStream_t s) {
 //   projections, N = 384 models) and mid-sized M;  64 x 128: one or two clips (M = 1500 .. 3000) and tiny test shapes.
 constexpr int kSlots = 512;
 template <int EPI>
-int launch_epi(GemmArgs a, int terms, hipStream_t s) {
+int launch_epi(GemmArgs a, int prec, hipStream_t s) {
+  if (prec == PREC_F16F8) {
+    if constexpr (EPI == EPI_BF16_GELU_SAVE || EPI == EPI_BF16_DGELU) return awt_fail(AWT_ERR_INVALID, "gemm: the training epilogues have no f16f8 form");
+    else {
+      const int64_t t256f = (int64_t)((a.M + 127) / 128) * (a.N / 256);
+      int tile = g_force_tile;
+      if (!tile) tile = (a.N % 256 == 0 && t256f >= kSlots) ? 256 : 128;
+      if (tile == 256 && a.N % 256 == 0) return launch_f8<EPI, CfgF8W4>(a, s);
+      return launch_f8<EPI, CfgF8Sq>(a, s);
+    }
+  }
+  const int terms = prec_products(prec);
+  if (prec == PREC_F16X3) {      // fp16 hi / lo planes on the same kernels
+    const int64_t t256h = (int64_t)((a.M + 127) / 128) * (a.N / 256), t128h = (int64_t)((a.M + 127) / 128) * (a.N / 128);
+    int tile = g_force_tile;
+    if (!tile) tile = (a.N % 256 == 0 && t256h >= kSlots) ? 256 : (t128h >= kSlots ? 128 : 64);
+    if (tile == 256 && a.N % 256 != 0) tile = 128;
+    if (tile == 256) return launch_one<3, 32, EPI, CfgW4, true>(a, s);
+    if (tile == 128) return launch_one<3, 32, EPI, Cfg128, true>(a, s);
+    return launch_one<3, 64, EPI, Cfg64, true>(a, s);
+  }
   const int64_t t256 = (int64_t)((a.M + 127) / 128) * (a.N / 256), t128 = (int64_t)((a.M + 127) / 128) * (a.N / 128);
   int tile = g_force_tile;
   if (!tile) tile = (a.N % 256 == 0 && t256 >= kSlots) ? 256 : (t128 >= kSlots ? 128 : 64);
@@ -409,11 +712,12 @@ int launch_epi(GemmArgs a, int terms, hipStream_t s) {
 
 void awt_gemm_force_tile(int t) { g_force_tile = t; }
 
-int launch_gemm(awt_ctx* c, int M, int N, const GemmSeg* segs, int nseg, int terms, GemmEpilogue epi, const GemmOut& out,
+int launch_gemm(awt_ctx* c, int M, int N, const GemmSeg* segs, int nseg, int prec, GemmEpilogue epi, const GemmOut& out,
                 hipStream_t s) {
   AWT_REQUIRE(M > 0 && N > 0 && N % 128 == 0, AWT_ERR_INVALID, "gemm: N must be a positive multiple of 128");
   AWT_REQUIRE(nseg >= 1 && nseg <= kMaxSeg, AWT_ERR_INVALID, "gemm: 1..3 K-segments");
-  AWT_REQUIRE(terms == 1 || terms == 3, AWT_ERR_INVALID, "gemm: terms must be 1 or 3");
+  AWT_REQUIRE(prec == PREC_BF16 || prec == PREC_BF16X3 || prec == PREC_F16X3 || prec == PREC_F16F8, AWT_ERR_INVALID, "gemm: unknown operand precision");
+  const int terms = prec_products(prec);
   AWT_REQUIRE(c && c->zeros, AWT_ERR_INVALID, "gemm: context without a zero page");
   static const bool env_read = [] { if (const char* e = getenv("AWT_GEMM_GROUP_N")) g_group_n = std::max(0, atoi(e)); return true; }();   // tile-order experiments (tools/)
   (void)env_read;
@@ -423,7 +727,9 @@ int launch_gemm(awt_ctx* c, int M, int N, const GemmSeg* segs, int nseg, int ter
   for (int i = 0; i < nseg; ++i) {
     a.seg[i] = segs[i];
     AWT_REQUIRE(segs[i].K > 0 && segs[i].K % 64 == 0, AWT_ERR_INVALID, "gemm: every K-segment must be a positive multiple of 64");
-    AWT_REQUIRE(segs[i].a_hi && segs[i].w_hi && (terms == 1 || (segs[i].a_lo && segs[i].w_lo)), AWT_ERR_INVALID, "gemm: null operand plane");
+    if (prec == PREC_F16F8) AWT_REQUIRE(segs[i].a_hi && segs[i].w_hi && segs[i].a8 && segs[i].al8 && segs[i].w8 && segs[i].wl8 && segs[i].w_ksteps % 2 == 0 && segs[i].w_k0 % 2 == 0,
+                                        AWT_ERR_INVALID, "gemm (f16f8): null operand plane or a K-segment that is not 64-aligned in its weight matrix");
+    else AWT_REQUIRE(segs[i].a_hi && segs[i].w_hi && (terms == 1 || (segs[i].a_lo && segs[i].w_lo)), AWT_ERR_INVALID, "gemm: null operand plane");
     AWT_REQUIRE(segs[i].lda % 8 == 0 && segs[i].w_ksteps > 0 && segs[i].w_k0 >= 0 && segs[i].w_k0 + segs[i].K / 32 <= segs[i].w_ksteps, AWT_ERR_INVALID,
                 "gemm: lda must be a multiple of 8 and the segment must lie inside its fragment-major weight matrix");
     AWT_REQUIRE(segs[i].rows_out > 0 && segs[i].rows_in > 0, AWT_ERR_INVALID, "gemm: bad row map");
@@ -431,14 +737,14 @@ int launch_gemm(awt_ctx* c, int M, int N, const GemmSeg* segs, int nseg, int ter
   }
   ProfScope prof(c, AWT_PROF_GEMM, s, 2.0 * (double)M * (double)out.n_valid * ksum);
   switch (epi) {
-    case EPI_F32: return launch_epi<EPI_F32>(a, terms, s);
-    case EPI_F32_RESID: return launch_epi<EPI_F32_RESID>(a, terms, s);
-    case EPI_BF16: return launch_epi<EPI_BF16>(a, terms, s);
-    case EPI_BF16_GELU: return launch_epi<EPI_BF16_GELU>(a, terms, s);
-    case EPI_QKV: return launch_epi<EPI_QKV>(a, terms, s);
-    case EPI_F32_GELU_POS: return launch_epi<EPI_F32_GELU_POS>(a, terms, s);
-    case EPI_BF16_GELU_SAVE: return launch_epi<EPI_BF16_GELU_SAVE>(a, terms, s);
-    case EPI_BF16_DGELU: return launch_epi<EPI_BF16_DGELU>(a, terms, s);
+    case EPI_F32: return launch_epi<EPI_F32>(a, prec, s);
+    case EPI_F32_RESID: return launch_epi<EPI_F32_RESID>(a, prec, s);
+    case EPI_BF16: return launch_epi<EPI_BF16>(a, prec, s);
+    case EPI_BF16_GELU: return launch_epi<EPI_BF16_GELU>(a, prec, s);
+    case EPI_QKV: return launch_epi<EPI_QKV>(a, prec, s);
+    case EPI_F32_GELU_POS: return launch_epi<EPI_F32_GELU_POS>(a, prec, s);
+    case EPI_BF16_GELU_SAVE: return launch_epi<EPI_BF16_GELU_SAVE>(a, prec, s);
+    case EPI_BF16_DGELU: return launch_epi<EPI_BF16_DGELU>(a, prec, s);
   }
   return awt_fail(AWT_ERR_INVALID, "gemm: unknown epilogue");
 }

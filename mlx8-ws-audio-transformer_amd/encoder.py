@@ -26,7 +26,12 @@ import torch.nn as nn
 from . import _lib
 from .weights import EncoderConfig, LoraSpec, encoder_param_shapes, init_encoder_weights, init_lora_weights, lora_param_shapes
 
-PRECISIONS = {"bf16": 1, "bf16x3": 3}
+# operand precision modes (csrc/common.h PREC_*):
+#   bf16    one bf16 MFMA per fragment pair (fast; misses the 1e-3 bound)
+#   bf16x3  split-bf16, three bf16 MFMAs (2^-17 per operand; the training path's format)
+#   fp16x3  split-fp16, three fp16 MFMAs (2^-23 per operand: within fp32's own noise of the reference, also under 30x outlier gains)
+#   f16f8   fp16 main product + the two cross terms on the block-scaled e4m3 MFMA: two MFMA-equivalents (2^-16 per operand)
+PRECISIONS = {"bf16": 1, "bf16x3": 3, "fp16x3": 4, "f16f8": 5}
 
 
 @dataclass
@@ -117,6 +122,8 @@ class NativeWhisperEncoder(nn.Module):
             raise ValueError(f"precision must be one of {sorted(PRECISIONS)}")
         if cfg.head_dim != 64:
             raise ValueError("the native attention kernel is specialised for head_dim 64 (every Whisper size)")
+        if trainable and precision not in ("bf16", "bf16x3"):
+            raise ValueError("trainable=True keeps its activations as bf16 planes: precision must be 'bf16x3' or 'bf16'")
         if trainable and (lora is None or not set(lora.targets) <= {"q_proj", "k_proj", "v_proj"}):
             raise ValueError("trainable=True needs LoRA adapters, on q_proj / k_proj / v_proj only")
         self.cfg = cfg

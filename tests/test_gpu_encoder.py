@@ -56,6 +56,22 @@ def test_encoder_fast_bf16_mode_envelope(name, trimmed):
     assert e["max_abs"] < FAST_TOL["max_abs"] and e["rel_l2"] < FAST_TOL["rel_l2"], e
 
 
+# the other operand modes that meet the bound (encoder.PRECISIONS): same oracle, same bound, measured error printed
+@pytest.mark.parametrize("precision", ["fp16x3", "f16f8"])
+@pytest.mark.parametrize("name,trimmed,batch", [("mini", True, 2), ("tiny", True, 2), ("tiny", False, 2), ("small", True, 2), ("small", False, 2),
+                                                ("base", False, 1), ("large-v3", True, 1)])
+def test_encoder_other_parity_modes_vs_oracle(precision, name, trimmed, batch):
+    cfg = wts.config(name, trimmed)
+    W = wts.init_encoder_weights(cfg, 0, "test")
+    mel = _mel(cfg, batch)
+    out = _native(cfg, precision)(torch.from_numpy(mel).cuda()).last_hidden_state.cpu().numpy()
+    ref = oracle_enc.encoder_forward(W, mel, cfg.heads).numpy()
+    e = oracle_enc.error_norms(out, ref)
+    print(precision, name, trimmed, e)
+    assert e["max_abs"] < PARITY_TOL, e
+    assert e["max_abs"] < (2e-4 if precision == "fp16x3" else 5e-4), e      # fp32 oracle noise ~1e-5..1e-4 at these sizes
+
+
 def test_chunking_is_invisible():
     cfg = wts.config("tiny", True)
     mel = torch.from_numpy(_mel(cfg, 5)).cuda()

@@ -12,11 +12,11 @@ def _rand(shape, seed, scale=1.0):
 
 
 # tolerances: split-bf16 products carry ~2^-16 relative operand error, single bf16 ~2^-8
-TOL = {"bf16x3": 2e-5, "bf16": 1.5e-2}
+TOL = {"bf16x3": 2e-5, "bf16": 1.5e-2, "fp16x3": 2e-6, "f16f8": 6e-5}
 
 
 @pytest.mark.parametrize("tile", [0, 64, 128, 256])                    # 0 = chosen from the shape; the others force each block tiling
-@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16", "fp16x3", "f16f8"])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 256, 192), (1500, 384, 768), (77, 128, 3072),
                                    (2500, 768, 768), (4096, 256, 128), (3000, 2304, 768)])
 def test_linear(precision, M, N, K, tile):
@@ -29,6 +29,7 @@ def test_linear(precision, M, N, K, tile):
         _lib.tuning_set("gemm_tile", 0)
     ref = torch.nn.functional.linear(x.double(), w.double(), b.double())
     err = (y.double() - ref).abs().max().item()
+    print(precision, (M, N, K), tile, "max-abs", err, "ref max", ref.abs().max().item())
     assert err < TOL[precision] * max(1.0, ref.abs().max().item()), err
 
 
@@ -47,6 +48,8 @@ def test_linear_identity_with_asymmetric_weight():
     w = (torch.arange(128 * 128, dtype=torch.float32).reshape(128, 128) % 251 - 125).cuda() / 64
     y = ops.linear(x, w, None, "bf16x3")
     assert torch.equal(y, w.t().contiguous())
+    for precision in ("fp16x3", "f16f8"):      # the weights here are multiples of 1/64 below 2: exact in fp16
+        assert torch.equal(ops.linear(x, w, None, precision), w.t().contiguous()), precision
 
 
 @pytest.mark.parametrize("d", [128, 384, 512, 768])
