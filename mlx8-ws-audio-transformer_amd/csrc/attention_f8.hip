@@ -24,6 +24,8 @@ extern int g_attn_shape;
 
 namespace {
 
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+
 constexpr int KB = 64;               // keys per tile
 constexpr int PL16 = KB * 64 * 2;    // 8 KiB: [64 keys][64 dims] fp16
 constexpr int PL8 = KB * 64;         // 4 KiB: [64 keys][64 dims] e4m3
@@ -308,6 +310,294 @@ __global__ __launch_bounds__(64 * NW, (QT == 1 && NW == 6) ? 3 : 2) void attenti
   }
 }
 
+// ------------------------------------------------------------------------------------------------ software-pipelined form
+// The kernel above runs, per wave and K/V tile, 1024 cycles of MFMA and ~350 VALU instructions (~1400 issue cycles) strictly one
+// after the other, and the two waves of a SIMD do not interleave on their own: 3000 cycles per tile where the matrix pipe
+// needs 1024.  Here each wave overlaps them itself: iteration k issues the S^T = K Q^T MFMAs of tile k + 1 with the softmax
+// VALU work of tile k in the gaps between them (an MFMA occupies the issue port for 8 of its 32 / 64 cycles), then the
+// O^T += V^T P^T MFMAs of tile k with the e4m3 packing of P between them.  K is therefore staged two tiles ahead and consumed
+// one iteration early (K(k + 2) lands in the buffer K(k) left in iteration k - 1), V one tile ahead; still two 32 KB stages.
+// One 32-query tile per wave (the second accumulator tile takes the registers of the second query tile), four waves.
+// K (or V) planes of tile kt -> stage: 8 groups of 64 sixteen-byte slots in the fp16 plane, 4 in each e4m3 plane.  Four waves: two
+// fp16 groups and one group of each e4m3 plane per wave; eight waves: one fp16 group and one e4m3 group (waves 0-3 hi8, 4-7 lo8).
+template <int NW, bool ISK>
+__device__ __forceinline__ void stage_kv1(const Attn8Args& a, int64_t head_off, int kt, char* stage, int wave, int lane) {
+  const int64_t tile_off = head_off + (int64_t)kt * (KB * 64);
+  const int last = a.S - 1 - kt * KB;
+  const bf16_t* p16 = (ISK ? a.k16 : a.v16) + tile_off;
+  const uint8_t* p8 = (ISK ? a.k8 : a.v8) + tile_off;
+  const uint8_t* pl8 = (ISK ? a.kl8 : a.vl8) + tile_off;
+  constexpr int O16 = ISK ? OFF_K16 : OFF_V16, O8 = ISK ? OFF_K8 : OFF_V8, OL8 = ISK ? OFF_KL8 : OFF_VL8;
+#pragma unroll
+  for (int g0 = 0; g0 < 8; g0 += NW) {
+    const int p = (g0 + wave) * 64 + lane, row = p >> 3;
+    glds16(p16 + (unsigned)(min(row, last) * 64 + (((p & 7) ^ swz16(row)) << 3)), stage + O16 + (g0 + wave) * 1024);
+  }
+  const int grp = wave & 3;
+  const int p = grp * 64 + lane, row = p >> 2;
+  const unsigned off = (unsigned)(min(row, last) * 64 + (((p & 3) ^ (ISK ? swz_k8(row) : swz_v8(row))) << 4));
+  if (NW == 4) {
+    glds16(p8 + off, stage + O8 + grp * 1024);
+    glds16(pl8 + off, stage + OL8 + grp * 1024);
+  } else {
+    glds16((wave < 4 ? p8 : pl8) + off, stage + (wave < 4 ? O8 : OL8) + grp * 1024);
+  }
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 2) void attention_f16f8_pipe_kernel(Attn8Args a) {
+  constexpr int QB = 32 * NW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nqb = (a.S + QB - 1) / QB;
+  const int nwg = nqb * a.B * a.H;
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int qd = nwg >> 3, rm = nwg & 7;
+  const int logical = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx;
+  const int bh = logical / nqb;
+  const int b = bh / a.H, h = bh - b * a.H;
+  const int q0 = (logical - bh * nqb) * QB + wave * 32;
+  const int64_t head_off = (int64_t)bh * a.S * 64;
+  const int ql = lane & 31, half = lane >> 5;
+
+  bf16x8 q16[4];
+  i32x8 q8, ql8;
+  {
+    int q = q0 + ql; q = q < a.S ? q : a.S - 1;
+    const int64_t off = head_off + (int64_t)q * 64;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) q16[ks] = *reinterpret_cast<const bf16x8*>(a.q16 + off + half * 8 + ks * 16);
+    const uint4 x0 = *reinterpret_cast<const uint4*>(a.q8 + off + half * 32), x1 = *reinterpret_cast<const uint4*>(a.q8 + off + half * 32 + 16);
+    const uint4 y0 = *reinterpret_cast<const uint4*>(a.ql8 + off + half * 32), y1 = *reinterpret_cast<const uint4*>(a.ql8 + off + half * 32 + 16);
+    q8 = (i32x8){(int)x0.x, (int)x0.y, (int)x0.z, (int)x0.w, (int)x1.x, (int)x1.y, (int)x1.z, (int)x1.w};
+    ql8 = (i32x8){(int)y0.x, (int)y0.y, (int)y0.z, (int)y0.w, (int)y1.x, (int)y1.y, (int)y1.z, (int)y1.w};
+  }
+  f32x16 oacc[2] = {(f32x16){}, (f32x16){}};
+  float m_run = -1.0e30f, l_run = 0.f;
+
+  int koff[4], k8off[2];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) koff[ks] = ql * 128 + (((2 * ks + half) ^ swz16(ql)) << 4);
+#pragma unroll
+  for (int c = 0; c < 2; ++c) k8off[c] = ql * 64 + (((2 * half + c) ^ swz_k8(ql)) << 4);
+  const int g = lane >> 4, li = lane & 15, qq = li >> 2, pp = li & 3;
+  const int vkey = 4 * (g >> 1) + qq;
+  const int voff = vkey * 128 + (((2 * (g & 1) + (pp >> 1)) ^ swz16(vkey)) << 4) + 8 * (pp & 1);
+  const int voffx = voff ^ 64;
+  const int tq = li >> 1, tp = li & 1;
+  const int v8key = 8 * (tq >> 2) + (tq & 3) + 4 * (g >> 1);
+  const int v8off = v8key * 64 + ((((g & 1)) ^ swz_v8(v8key)) << 4) + 8 * tp;
+
+  const int ntiles = (a.S + KB - 1) / KB;
+
+  // ---- the MFMA slots of one iteration, in issue order.  Every slot reads its LDS operand TWO slots ahead of its MFMA into a
+  // three-entry register ring (an LDS read takes 64-128 cycles to return: read just before use, the 28 reads of a tile cost
+  // more than its 24 MFMAs), and carries one chunk of VALU work that is issued between the read and the MFMA.
+  //   slots  0..11  S(kt + 1)^T = K Q^T: per 32-key sub-tile the two e4m3 cross terms, then the four fp16 k-steps
+  //   slots 12..19  O^T += V16^T P16^T  (kt2, s2, et)
+  //   slots 20..23  O^T += V8^T Pl8^T + Vl8^T P8^T  (et x 2)
+  constexpr int NSLOT = 24, DEPTH = 2;
+  auto read_slot = [&](auto slot_t, const char* kst, const char* vst, i32x8& f) {
+    constexpr int SLOT = decltype(slot_t)::value;
+    if constexpr (SLOT < 12) {
+      constexpr int kt2 = SLOT / 6, w = SLOT % 6;
+      if constexpr (w < 2) {
+        const char* pl = kst + (w == 0 ? OFF_K8 : OFF_KL8) + kt2 * 2048;
+        const uint4 x0 = *reinterpret_cast<const uint4*>(pl + k8off[0]), x1 = *reinterpret_cast<const uint4*>(pl + k8off[1]);
+        f = (i32x8){(int)x0.x, (int)x0.y, (int)x0.z, (int)x0.w, (int)x1.x, (int)x1.y, (int)x1.z, (int)x1.w};
+      } else {
+        const uint4 x0 = *reinterpret_cast<const uint4*>(kst + OFF_K16 + koff[w - 2] + kt2 * 4096);
+        f[0] = (int)x0.x; f[1] = (int)x0.y; f[2] = (int)x0.z; f[3] = (int)x0.w;
+      }
+    } else if constexpr (SLOT < 20) {
+      constexpr int I = SLOT - 12, kt2 = I >> 2, s2 = (I >> 1) & 1, et = I & 1;
+      constexpr int cst = kt2 * 4096 + s2 * 2048;
+      const int off0 = (et == 0 ? voff : voffx) + cst;
+      const int off1 = (et == 0 ? voffx : voff) + cst + 1024;
+      const i32x2 va = __builtin_bit_cast(i32x2, tr_read16(vst + OFF_V16 + off0)), vb = __builtin_bit_cast(i32x2, tr_read16(vst + OFF_V16 + off1));
+      f[0] = va[0]; f[1] = va[1]; f[2] = vb[0]; f[3] = vb[1];
+    } else {
+      constexpr int I = SLOT - 20, et = I >> 1, lo = I & 1;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        const i32x2 x = tr_read8(vst + (lo ? OFF_VL8 : OFF_V8) + ((v8off ^ (et << 5)) + n * 1024));
+        f[2 * n] = x[0]; f[2 * n + 1] = x[1];
+      }
+    }
+  };
+
+  // prologue: K(0), V(0) -> stage 0, K(1) -> stage 1; S(0)
+  stage_kv1<NW, true>(a, head_off, 0, smem, wave, lane);
+  stage_kv1<NW, false>(a, head_off, 0, smem, wave, lane);
+  if (ntiles > 1) stage_kv1<NW, true>(a, head_off, 1, smem + STAGE, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  f32x16 sa[2], sb[2];
+  auto qk_mma = [&](auto slot_t, const i32x8& f, f32x16 (&sn)[2]) {
+    constexpr int SLOT = decltype(slot_t)::value, kt2 = SLOT / 6, w = SLOT % 6;
+    if constexpr (w == 0) sn[kt2] = mfma32_f8<e8m0(-kF8KV), e8m0(-kF8Q - kF8Lo)>(f, ql8, (f32x16){});
+    else if constexpr (w == 1) sn[kt2] = mfma32_f8<e8m0(-kF8KV - kF8Lo), e8m0(-kF8Q)>(f, q8, sn[kt2]);
+    else {
+      const bf16x8 kh = __builtin_bit_cast(bf16x8, (i32x4_t){f[0], f[1], f[2], f[3]});
+      sn[kt2] = mfma32<true>(kh, q16[w - 2], sn[kt2]);
+    }
+  };
+  {
+    i32x8 ring[3];
+    read_slot(std::integral_constant<int, 0>{}, smem, smem, ring[0]);
+    read_slot(std::integral_constant<int, 1>{}, smem, smem, ring[1]);
+    [&]<int... I>(std::integer_sequence<int, I...>) {
+      ([&] {
+        if constexpr (I + DEPTH < 12) read_slot(std::integral_constant<int, I + DEPTH>{}, smem, smem, ring[(I + DEPTH) % 3]);
+        qk_mma(std::integral_constant<int, I>{}, ring[I % 3], sa);
+      }(), ...);
+    }(std::make_integer_sequence<int, 12>{});
+  }
+
+  // one iteration: softmax + PV of tile kt (scores in sc), and -- unless LAST -- the scores of tile kt + 1 into sn
+  auto iter = [&](auto last_t, auto tail_t, int kt, f32x16 (&sc)[2], f32x16 (&sn)[2]) {
+    constexpr bool LAST = decltype(last_t)::value, TAIL = decltype(tail_t)::value;
+    constexpr int FIRST = LAST ? 12 : 0;                  // the last tile has no next scores to compute
+    const char* cur = smem + (kt & 1) * STAGE;            // V(kt) lives here; K(kt + 2) is staged here
+    const char* oth = smem + ((kt + 1) & 1) * STAGE;      // K(kt + 1) lives here; V(kt + 1) is staged here
+#ifndef AWT_DIAG8_NO_STAGE   // AWT_DIAG8_*: timing-only builds (tools/build_attn8_variants.sh), wrong results, never shipped
+    if constexpr (!LAST) {
+      if (kt + 2 < ntiles) stage_kv1<NW, true>(a, head_off, kt + 2, const_cast<char*>(cur), wave, lane);
+      stage_kv1<NW, false>(a, head_off, kt + 1, const_cast<char*>(oth), wave, lane);
+    }
+#endif
+    bf16x8 p16[4];
+    i32x8 p8, pl8;
+    float tmax = -1.0e30f, m_new, alpha, psum = 0.f;
+    // VALU chunks: softmax of tile kt (chunks 0..11), e4m3 packing of P (chunks 12..19)
+    auto valu_chunk = [&](auto c_t) {
+      constexpr int C = decltype(c_t)::value;
+      if constexpr (C < 2) {                       // running maximum over sub-tile C
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          if (TAIL) {
+            const int key = kt * KB + C * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            sc[C][r] = key < a.S ? sc[C][r] : -1.0e30f;
+          }
+          tmax = fmaxf(tmax, sc[C][r]);
+        }
+        if constexpr (C == 1) {
+          tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+          m_new = fmaxf(m_run, tmax);
+          alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+          m_run = m_new;
+        }
+      } else if constexpr (C < 10) {               // exponentials of four accumulator registers, fp16 fragment halves
+        constexpr int e = C - 2, kt2 = e >> 2, r4 = e & 3;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float pv = __builtin_amdgcn_exp2f(sc[kt2][4 * r4 + j] - m_new);
+          sc[kt2][4 * r4 + j] = pv;
+          psum += pv;
+          p16[2 * kt2 + (r4 >> 1)][4 * (r4 & 1) + j] = (short)f32_to_f16(pv);
+        }
+      } else if constexpr (C < 12) {               // rescale of one output tile
+        constexpr int et = C - 10;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[et][r] *= alpha;
+        if constexpr (et == 1) l_run = l_run * alpha + psum;
+      } else if constexpr (C < 20) {               // four accumulator registers -> one dword of each e4m3 operand
+        constexpr int I = C - 12, c2 = I >> 2, r4 = I & 3;
+        float lo[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lo[j] = __builtin_fmaf(f16_to_f32((bf16_t)p16[2 * c2 + (r4 >> 1)][4 * (r4 & 1) + j]), -1.0f, sc[c2][4 * r4 + j]);
+        p8[4 * c2 + r4] = fp8x4_scaled<kF8P>(sc[c2][4 * r4], sc[c2][4 * r4 + 1], sc[c2][4 * r4 + 2], sc[c2][4 * r4 + 3]);
+        pl8[4 * c2 + r4] = fp8x4_scaled<kF8P + kF8Lo>(lo[0], lo[1], lo[2], lo[3]);
+      }
+    };
+    auto mma = [&](auto slot_t, const i32x8& f) {
+      constexpr int SLOT = decltype(slot_t)::value;
+      if constexpr (SLOT < 12) qk_mma(slot_t, f, sn);
+      else if constexpr (SLOT < 20) {
+        constexpr int I = SLOT - 12, kt2 = I >> 2, s2 = (I >> 1) & 1, et = I & 1;
+        const bf16x8 vh = __builtin_bit_cast(bf16x8, (i32x4_t){f[0], f[1], f[2], f[3]});
+        oacc[et] = mfma32<true>(vh, p16[2 * kt2 + s2], oacc[et]);
+      } else {
+        constexpr int I = SLOT - 20, et = I >> 1, lo = I & 1;
+        if constexpr (lo == 0) oacc[et] = mfma32_f8<e8m0(-kF8KV), e8m0(-kF8P - kF8Lo)>(f, pl8, oacc[et]);
+        else oacc[et] = mfma32_f8<e8m0(-kF8KV - kF8Lo), e8m0(-kF8P)>(f, p8, oacc[et]);
+      }
+    };
+    i32x8 ring[3];
+    read_slot(std::integral_constant<int, FIRST>{}, oth, cur, ring[FIRST % 3]);
+    read_slot(std::integral_constant<int, FIRST + 1>{}, oth, cur, ring[(FIRST + 1) % 3]);
+    if constexpr (LAST) {   // no S^T MFMAs to hide the softmax behind
+      [&]<int... C>(std::integer_sequence<int, C...>) { (valu_chunk(std::integral_constant<int, C>{}), ...); }(std::make_integer_sequence<int, 12>{});
+    }
+    [&]<int... J>(std::integer_sequence<int, J...>) {
+      ([&] {
+        constexpr int I = FIRST + J;
+        if constexpr (I + DEPTH < NSLOT) read_slot(std::integral_constant<int, I + DEPTH>{}, oth, cur, ring[(I + DEPTH) % 3]);
+        if constexpr (!LAST || I >= 12) valu_chunk(std::integral_constant<int, I>{});
+        __builtin_amdgcn_sched_barrier(0);
+        mma(std::integral_constant<int, I>{}, ring[I % 3]);
+        __builtin_amdgcn_sched_barrier(0);
+      }(), ...);
+    }(std::make_integer_sequence<int, NSLOT - FIRST>{});
+#ifndef AWT_DIAG8_NO_DMAWAIT
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    __syncthreads();
+  };
+  // tiles in pairs so that the two score buffers swap roles without register copies
+  int kt = 0;
+  for (; kt + 2 < ntiles; kt += 2) {
+    iter(std::false_type{}, std::false_type{}, kt, sa, sb);
+    iter(std::false_type{}, std::false_type{}, kt + 1, sb, sa);
+  }
+  if (kt + 2 == ntiles) {
+    iter(std::false_type{}, std::false_type{}, kt, sa, sb);
+    if (a.S % KB) iter(std::true_type{}, std::true_type{}, kt + 1, sb, sa);
+    else iter(std::true_type{}, std::false_type{}, kt + 1, sb, sa);
+  } else {
+    if (a.S % KB) iter(std::true_type{}, std::true_type{}, kt, sa, sb);
+    else iter(std::true_type{}, std::false_type{}, kt, sa, sb);
+  }
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = 1.0f / l_tot;
+  const int q = q0 + ql;
+  if (a.lse && q < a.S && half == 0) a.lse[(int64_t)bh * a.S + q] = m_run + __builtin_amdgcn_logf(l_tot);
+  if (q < a.S) {
+    const int64_t row = ((int64_t)b * a.S + q) * (a.H * 64) + h * 64;
+#pragma unroll
+    for (int et = 0; et < 2; ++et)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int e = 32 * et + 8 * g4 + 4 * half;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = oacc[et][4 * g4 + j] * inv;
+        if (a.o_f32) {
+          *reinterpret_cast<float4*>(a.o_f32 + row + e) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+          uint2 h16; unsigned hi8, lo8;
+          f16f8x4<kF8Act>(v, h16, hi8, lo8);
+          *reinterpret_cast<uint2*>(a.o16 + row + e) = h16;
+          *reinterpret_cast<unsigned*>(a.o8 + row + e) = hi8;
+          *reinterpret_cast<unsigned*>(a.ol8 + row + e) = lo8;
+        }
+      }
+  }
+}
+
+template <int NW>
+int launch_pipe(const Attn8Args& a, hipStream_t s) {
+  constexpr int lds = 2 * STAGE;
+  constexpr int QB = 32 * NW;
+  AWT_ONCE_PER_DEVICE(AWT_HIP_CHECK(hipFuncSetAttribute((const void*)attention_f16f8_pipe_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)));
+  dim3 grid(((a.S + QB - 1) / QB) * a.B * a.H);
+  hipLaunchKernelGGL(attention_f16f8_pipe_kernel<NW>, grid, dim3(64 * NW), lds, s, a);
+  AWT_HIP_CHECK(hipGetLastError());
+  return AWT_OK;
+}
+
 template <int QT, int NW>
 int launch_t(const Attn8Args& a, hipStream_t s) {
   constexpr int lds = 2 * STAGE;
@@ -337,8 +627,12 @@ int launch_attention_f16f8(awt_ctx* c, const F8Planes& q, const F8Planes& k, con
   if (shape == 1) return launch_t<1, 4>(a, s);
   if (shape == 2) return launch_t<2, 4>(a, s);
   if (shape == 3) return launch_t<1, 6>(a, s);
-  const int64_t wg6 = (int64_t)((S + 191) / 192) * B * H, wg1 = (int64_t)((S + 127) / 128) * B * H;
-  const double cost6 = (double)((wg6 + 511) / 512), cost1 = 0.7 * (double)((wg1 + 511) / 512);
-  if (cost1 < cost6) return launch_t<1, 4>(a, s);
-  return launch_t<1, 6>(a, s);
+  if (shape == 4) return launch_pipe<4>(a, s);
+  if (shape == 5) return launch_pipe<8>(a, s);
+  // measured at B = 64, H = 12, S = 1500 (tools/attn_bench.py): plain 4 x 32 queries 1.25 ms, 4 x 64 queries 1.40 ms (70 spilled
+  // registers), 6 x 32 queries 1.67 ms; software-pipelined 4 x 32 queries 1.15 ms, 8 x 32 queries (one workgroup per CU, half the
+  // K / V staging traffic) 1.13 ms.  Small grids take the four-wave form (twice the workgroups).
+  const int64_t wg8 = (int64_t)((S + 255) / 256) * B * H;
+  if (wg8 >= 256) return launch_pipe<8>(a, s);
+  return launch_pipe<4>(a, s);
 }

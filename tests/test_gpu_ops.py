@@ -78,26 +78,30 @@ def test_attention(precision, B, H, S):
     assert err < ATT_TOL[precision], err  # v_exp_f32 ~1 ulp; bf16 rounds q, k, v and P
 
 
-@pytest.mark.parametrize("shape", [1, 2, 3])
+@pytest.mark.parametrize("shape", [1, 2, 3, 4, 5])
 def test_attention_f16f8_workgroup_shapes(shape):
     """Every workgroup shape of the f16f8 attention kernel (4 x 32, 4 x 64, 6 x 32 queries) on a sequence with a tail tile."""
     from mlx8_ws_audio_transformer_amd import _lib, ops
-    B, H, S = 2, 2, 333
-    q, k, v = _rand((B, H, S, 64), 17, 0.35), _rand((B, H, S, 64), 18), _rand((B, H, S, 64), 19)
-    _lib.tuning_set("attn_shape", shape)
-    try:
-        o = ops.attention(q, k, v, "f16f8")
-    finally:
-        _lib.tuning_set("attn_shape", 0)
-    p = torch.softmax(q.double() @ k.double().transpose(2, 3), dim=-1)
-    ref = (p @ v.double()).transpose(1, 2).reshape(B, S, H * 64)
-    assert (o.double() - ref).abs().max().item() < ATT_TOL["f16f8"]
+    for S in (333, 64, 100, 128, 200, 1500):          # 6 / 1 / 2 / 2 / 4 / 24 key tiles, with and without a tail tile
+        B, H = 2, 2
+        q, k, v = _rand((B, H, S, 64), 17, 0.35), _rand((B, H, S, 64), 18), _rand((B, H, S, 64), 19)
+        _lib.tuning_set("attn_shape", shape)
+        try:
+            o = ops.attention(q, k, v, "f16f8")
+        finally:
+            _lib.tuning_set("attn_shape", 0)
+        p = torch.softmax(q.double() @ k.double().transpose(2, 3), dim=-1)
+        ref = (p @ v.double()).transpose(1, 2).reshape(B, S, H * 64)
+        assert (o.double() - ref).abs().max().item() < ATT_TOL["f16f8"], S
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "fp16x3", "f16f8"])
+@pytest.mark.parametrize("precision", ["bf16x3", "fp16x3", "f16f8", "f16f8-pipe"])
 def test_attention_online_softmax_rescale_branch(precision):
     # one key per late tile dominates one query's row: forces the running maximum to jump tile after tile
-    from mlx8_ws_audio_transformer_amd import ops
+    from mlx8_ws_audio_transformer_amd import _lib, ops
+    if precision == "f16f8-pipe":
+        _lib.tuning_set("attn_shape", 4)
+        precision = "f16f8"
     B, H, S = 1, 1, 448
     q, k, v = _rand((B, H, S, 64), 10, 0.2), _rand((B, H, S, 64), 11), _rand((B, H, S, 64), 12)
     for t, key in enumerate([70, 150, 260, 390]):
@@ -106,6 +110,7 @@ def test_attention_online_softmax_rescale_branch(precision):
     p = torch.softmax(q.double() @ k.double().transpose(2, 3), dim=-1)
     ref = (p @ v.double()).transpose(1, 2).reshape(B, S, 64)
     # logits reach ~170: fp32 ulp of the exp2 argument is ~1.5e-5; f16f8 carries the logits to 2^-16 relative: 170 * 2^-16 = 2.6e-3 in the exponent
+    _lib.tuning_set("attn_shape", 0)
     assert (o.double() - ref).abs().max().item() < (3e-4 if precision != "f16f8" else 1.5e-2)
 
 

@@ -9,7 +9,7 @@ B, H, S = 64, 12, 1500
 q, k, v = (torch.randn(B, H, S, 64, device="cuda") for _ in range(3))
 q *= 0.35
 ref = None
-for prec, shape in [("bf16x3", 0), ("fp16x3", 0), ("f16f8", 1), ("f16f8", 2), ("f16f8", 3), ("f16f8", 0), ("bf16", 0)]:
+for prec, shape in [("bf16x3", 0), ("fp16x3", 0), ("f16f8", 1), ("f16f8", 2), ("f16f8", 3), ("f16f8", 4), ("f16f8", 5), ("f16f8", 0), ("bf16", 0)]:
     _lib.tuning_set("attn_shape", shape)
     o = ops.attention(q, k, v, prec)
     if ref is None:
