@@ -321,23 +321,51 @@ def sweep_main(a):
     R.finish()
 
 
-def sample_power(torch, step, dev, steps=40):
-    """Queues `steps` more (untimed) steps and reads rocm-smi while the GPU works through them.  None if rocm-smi is missing."""
-    import re
-    try:
+class PowerSampler:
+    """rocm-smi in a helper process that is started BEFORE this process initialises the GPU (a GPU-initialised process must
+    not exec another program on this pool); `window()` runs untimed steps and returns the samples taken meanwhile."""
+
+    def __init__(self):
+        import tempfile
+        self.dir = tempfile.mkdtemp(prefix="awt_power_")
+        self.out, self.stop = os.path.join(self.dir, "samples.jsonl"), os.path.join(self.dir, "stop")
+        try:
+            self.proc = subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "power_sampler.py"), self.out, self.stop, str(os.getpid())],
+                                         stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        except Exception:
+            self.proc = None
+
+    def window(self, torch, step, dev, steps=60):
+        if self.proc is None:
+            return None
+        torch.cuda.synchronize(dev)
+        t0 = time.time()
         for _ in range(steps):
             step()
+        torch.cuda.synchronize(dev)
+        t1 = time.time()
         time.sleep(0.3)
-        txt = subprocess.run(["rocm-smi", "--showpower", "--showclocks"], capture_output=True, text=True, timeout=20).stdout
-        torch.cuda.synchronize(dev)
-        watts = [float(x) for x in re.findall(r"Power \(W\):\s*([0-9.]+)", txt)]
-        sclk = [int(x) for x in re.findall(r"sclk clock level:\s*\d+:\s*\((\d+)Mhz\)", txt)]
-        if not watts or not sclk:
+        rows = []
+        try:
+            for line in open(self.out):
+                r = json.loads(line)
+                if t0 + 0.3 <= r["t"] <= t1:
+                    rows.append(r)
+        except Exception:
             return None
-        return {"package_w": max(watts), "sclk_mhz": min(sclk), "note": "rocm-smi sampled once while the headline workload was running (untimed)"}
-    except Exception:
-        torch.cuda.synchronize(dev)
-        return None
+        if not rows:
+            return None
+        med = lambda v: sorted(v)[len(v) // 2]
+        return {"package_w": med([r["package_w"] for r in rows]), "sclk_mhz": med([r["sclk_mhz"] for r in rows]), "samples": len(rows),
+                "note": "median of rocm-smi samples taken by a helper process while %d untimed steps of the headline workload ran" % steps}
+
+    def close(self):
+        try:
+            open(self.stop, "w").close()
+            if self.proc is not None:
+                self.proc.wait(timeout=30)
+        except Exception:
+            pass
 
 
 def cpu_baseline_and_parity(a, torch, cfg, enc, pcm, pcm_host, out_first):
@@ -378,6 +406,7 @@ def cpu_baseline_and_parity(a, torch, cfg, enc, pcm, pcm_host, out_first):
 
 
 def encode_main(a):
+    sampler = PowerSampler() if (int(os.environ.get("RANK", "0")) == 0 and a.gpus == 1) else None   # before the GPU is initialised
     R = Ranks(a)
     torch, dev, rank, world = R.torch, R.dev, R.rank, R.world
     from mlx8_ws_audio_transformer_amd import _lib, synth, weights as wts
@@ -457,7 +486,7 @@ def encode_main(a):
     if rank == 0 and world == 1:
         # ---- package power and shader clock while the headline workload runs (rocm-smi in a child process, outside the timed
         #      region): the encoder sits at the package power limit, which is what caps roofline.frac
-        result["power"] = sample_power(torch, lambda: enc.encode_pcm(pcm), dev)
+        result["power"] = sampler.window(torch, lambda: enc.encode_pcm(pcm), dev) if sampler else None
         # ---- the other operand modes, reported beside the headline with all three error norms vs the headline's output
         if not a.no_fast_mode:
             side = {}
@@ -478,6 +507,8 @@ def encode_main(a):
         # ---- CPU baseline: the oracle (CPU restatement of the reference path) on this host's cores, bounded sample
         if not a.no_cpu_baseline:
             result["cpu_baseline"], result["parity"], _ = cpu_baseline_and_parity(a, torch, cfg, enc, pcm, pcm_host, out)
+    if sampler:
+        sampler.close()
     if rank == 0:
         print(json.dumps(result))
     R.finish()

@@ -229,6 +229,53 @@ __device__ __forceinline__ void store_out4(const GemmOut& o, int m, int n, float
   }
 }
 
+// Eight consecutive columns of one row in the f16f8 output format: 16-byte fp16 and 8-byte e4m3 stores (the 4-column form
+// writes 4-byte pieces of the e4m3 planes: twice the store instructions for the same bytes).  n is a multiple of 8, so the
+// eight columns never straddle a head or a q / k / v boundary of EPI_QKV.
+template <int EPI>
+__device__ __forceinline__ void store_out8_f8(const GemmOut& o, int m, int n, float4 acc0, float4 acc1, float4 side0, float4 side1, int M) {
+  static_assert(EPI != EPI_BF16_GELU_SAVE && EPI != EPI_BF16_DGELU, "training epilogues have no f16f8 form");
+  if (m >= M || n >= o.n_valid) return;
+  float v[8] = {acc0.x, acc0.y, acc0.z, acc0.w, acc1.x, acc1.y, acc1.z, acc1.w};
+  const float sd[8] = {side0.x, side0.y, side0.z, side0.w, side1.x, side1.y, side1.z, side1.w};
+  if (o.bias) {
+    const float4 b0 = *reinterpret_cast<const float4*>(o.bias + n), b1 = *reinterpret_cast<const float4*>(o.bias + n + 4);
+    v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+  }
+  if (EPI == EPI_F32 || EPI == EPI_F32_RESID || EPI == EPI_F32_GELU_POS) {
+    float* dst = o.f32 + (int64_t)m * o.ldo + n;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) v[t] = EPI == EPI_F32_RESID ? v[t] + sd[t] : (EPI == EPI_F32_GELU_POS ? gelu_erf(v[t]) + sd[t] : v[t]);
+    *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    return;
+  }
+  int64_t off;
+  float f8s = pow2f(kF8Act);
+  if (EPI == EPI_QKV) {
+    const int d = o.H * 64;
+    const int which = n / d, within = n - which * d;
+    f8s = which == 0 ? pow2f(kF8Q) : pow2f(kF8KV);
+    const int h = within >> 6, e = within & 63;
+    const int b = m / o.S, s = m - b * o.S;
+    if (which == 0) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) v[t] *= o.scale;
+    }
+    off = (int64_t)which * o.plane_stride + (((int64_t)b * o.H + h) * o.S + s) * 64 + e;
+  } else {
+    off = (int64_t)m * o.ldo + n;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) v[t] = EPI == EPI_BF16_GELU ? gelu_erf(v[t]) : v[t] * o.scale;
+  }
+  bf16_t h[8]; float l[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) { h[t] = f32_to_f16(v[t]); l[t] = (v[t] - f16_to_f32(h[t])) * (f8s * pow2f(kF8Lo)); v[t] *= f8s; }
+  *reinterpret_cast<uint4*>(o.hi + off) = make_uint4(pack2(h[0], h[1]), pack2(h[2], h[3]), pack2(h[4], h[5]), pack2(h[6], h[7]));
+  *reinterpret_cast<uint2*>(o.hi8 + off) = make_uint2(fp8x4<0>(v[0], v[1], v[2], v[3]), fp8x4<0>(v[4], v[5], v[6], v[7]));
+  *reinterpret_cast<uint2*>(o.lo8 + off) = make_uint2(fp8x4<0>(l[0], l[1], l[2], l[3]), fp8x4<0>(l[4], l[5], l[6], l[7]));
+}
+
 template <int TERMS, int BK, int EPI, class CFG, bool F16>
 __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, 2) void gemm_kernel(GemmArgs g) {
   using T = Tile<TERMS, BK, CFG>;
@@ -601,12 +648,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f8_kernel(GemmArgs g) {
   ktile(std::false_type{}, ktiles - 1);
 
   // ---- epilogue: each wave transposes one 32-row x 64-column strip at a time through a private LDS patch (32 x 32 C/D
-  // layout: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)) and writes whole 256-byte row segments.
+  // layout: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)); a lane then owns EIGHT consecutive columns of a row
+  // (8 lanes per row, 8 rows per pass): 32-byte fp32 / 16-byte fp16 / 8-byte e4m3 stores, whole 256-byte row segments per plane.
   static_assert(TN == 2, "epilogue strips are 64 columns wide");
-  constexpr int PITCH = 68;
-  float* patch = reinterpret_cast<float*>(smem) + wave * (32 * PITCH);      // 8704 B per wave
-  const int frow = lane & 15, fq = lane >> 4;
-  const int em0 = m0 + wr * TM * 32, en = n0 + wc * 64 + frow * 4;
+  constexpr int PITCH = 72;   // floats: 288-byte rows keep the two 16-byte reads of a lane 16-byte aligned
+  float* patch = reinterpret_cast<float*>(smem) + wave * (32 * PITCH);      // 9216 B per wave
+  const int c8 = (lane & 7) * 8, r8 = lane >> 3;
+  const int em0 = m0 + wr * TM * 32, en = n0 + wc * 64 + c8;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -615,17 +663,17 @@ __global__ __launch_bounds__(256, 2) void gemm_f8_kernel(GemmArgs g) {
       for (int rr = 0; rr < 16; ++rr) patch[((rr & 3) + 8 * (rr >> 2) + 4 * half) * PITCH + j * 32 + r32] = acc[i][j][rr];
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    float4 side[4][2];
 #pragma unroll
-    for (int h2 = 0; h2 < 2; ++h2) {       // two groups of four rows per lane: side inputs of a group are loaded together
-      float4 side[4];
+    for (int it = 0; it < 4; ++it) {
+      side[it][0] = load_side4<EPI>(g.out, em0 + i * 32 + r8 + 8 * it, en, g.M);
+      side[it][1] = load_side4<EPI>(g.out, em0 + i * 32 + r8 + 8 * it, en + 4, g.M);
+    }
 #pragma unroll
-      for (int it = 0; it < 4; ++it) side[it] = load_side4<EPI>(g.out, em0 + i * 32 + fq + 4 * (4 * h2 + it), en, g.M);
-#pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int rl = fq + 4 * (4 * h2 + it);
-        const float4 v = *reinterpret_cast<const float4*>(patch + rl * PITCH + frow * 4);
-        store_out4<EPI, PREC_F16F8>(g.out, em0 + i * 32 + rl, en, v, side[it], g.M);
-      }
+    for (int it = 0; it < 4; ++it) {
+      const int rl = r8 + 8 * it;
+      const float4 v0 = *reinterpret_cast<const float4*>(patch + rl * PITCH + c8), v1 = *reinterpret_cast<const float4*>(patch + rl * PITCH + c8 + 4);
+      store_out8_f8<EPI>(g.out, em0 + i * 32 + rl, en, v0, v1, side[it][0], side[it][1], g.M);
     }
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -17,8 +17,9 @@ import csv, glob, json, sys, collections
 out, tag = sys.argv[1], sys.argv[2]
 sys.path.insert(0, "."); import bench
 def short(n):
-    for k in ("gemm_kernel", "attention_kernel", "layernorm_kernel", "logmel_stage1", "logmel_finalize", "im2col"):
-        if k in n: return k
+    for k, pats in (("gemm_kernel", ("gemm_kernel", "gemm_f8_kernel")), ("attention_kernel", ("attention_kernel", "attention_f16f8")), ("layernorm_kernel", ("layernorm_kernel",)),
+                    ("logmel_stage1", ("logmel_stage1",)), ("logmel_finalize", ("logmel_finalize",)), ("im2col", ("im2col",))):
+        if any(p in n for p in pats): return k
 cc = glob.glob(f"{out}/pmc_MFMA/**/*counter_collection.csv", recursive=True)
 kt = glob.glob(f"{out}/pmc_MFMA/**/*kernel_trace.csv", recursive=True)
 if cc and kt:
@@ -48,8 +49,9 @@ import csv, glob, json, sys, collections
 out, tag = sys.argv[1], sys.argv[2]
 sys.path.insert(0, "."); import bench
 def short(n):
-    for k in ("gemm_kernel", "attention_kernel", "layernorm_kernel", "logmel_stage1", "logmel_finalize", "im2col"):
-        if k in n: return k
+    for k, pats in (("gemm_kernel", ("gemm_kernel", "gemm_f8_kernel")), ("attention_kernel", ("attention_kernel", "attention_f16f8")), ("layernorm_kernel", ("layernorm_kernel",)),
+                    ("logmel_stage1", ("logmel_stage1",)), ("logmel_finalize", ("logmel_finalize",)), ("im2col", ("im2col",))):
+        if any(p in n for p in pats): return k
     return None
 res = collections.defaultdict(lambda: collections.defaultdict(list))
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
