@@ -7,7 +7,7 @@ encoder (B = 1 launches) and concatenates (model.py:96-121).  Here the whole bat
 """
 from __future__ import annotations
 
-from typing import List, Union
+from typing import Optional, List, Union
 
 import numpy as np
 import torch
@@ -19,7 +19,7 @@ from .weights import EncoderConfig, config as named_config
 
 
 class WhisperAudioEncoder(nn.Module):
-    def __init__(self, model_name: Union[str, EncoderConfig] = "base", freeze_encoder: bool = True, precision: str = "bf16x3",
+    def __init__(self, model_name: Union[str, EncoderConfig] = "base", freeze_encoder: bool = True, precision: Optional[str] = None,
                  device: str = "cuda", state_dict=None):
         super().__init__()
         cfg = model_name if isinstance(model_name, EncoderConfig) else named_config(str(model_name).split("whisper-")[-1])

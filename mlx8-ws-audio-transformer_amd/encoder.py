@@ -32,6 +32,7 @@ from .weights import EncoderConfig, LoraSpec, encoder_param_shapes, init_encoder
 #   fp16x3  split-fp16, three fp16 MFMAs (2^-23 per operand: within fp32's own noise of the reference, also under 30x outlier gains)
 #   f16f8   fp16 main product + the two cross terms on the block-scaled e4m3 MFMA: two MFMA-equivalents (2^-16 per operand)
 PRECISIONS = {"bf16": 1, "bf16x3": 3, "fp16x3": 4, "f16f8": 5}
+DEFAULT_PRECISION = "f16f8"
 
 
 @dataclass
@@ -111,10 +112,12 @@ def _attach(root: nn.Module, dotted: str, p: nn.Parameter) -> None:
 
 
 class NativeWhisperEncoder(nn.Module):
-    def __init__(self, cfg: EncoderConfig, precision: str = "bf16x3", lora: Optional[LoraSpec] = None,
+    def __init__(self, cfg: EncoderConfig, precision: Optional[str] = None, lora: Optional[LoraSpec] = None,
                  device: str = "cuda", chunk_clips: int = 0, seed: Optional[int] = 0, init_profile: str = "hf",
                  trainable: bool = False, backward_precision: Optional[str] = None):
         super().__init__()
+        if precision is None:       # default: the fastest mode that meets the 1e-3 bound; training keeps bf16 planes
+            precision = "bf16x3" if trainable else DEFAULT_PRECISION
         if backward_precision not in (None, precision, "bf16"):
             raise ValueError("backward_precision must be None (= precision) or 'bf16'")
         self.backward_precision = backward_precision

@@ -263,3 +263,20 @@ def weights_digest(weights: Dict[str, np.ndarray]) -> str:
         h.update(k.encode())
         h.update(np.ascontiguousarray(weights[k], dtype=np.float32).tobytes())
     return h.hexdigest()
+
+
+def with_outlier_channels(W: Dict[str, np.ndarray], cfg: "EncoderConfig", seed: int = 0, ln_gain: float = 30.0, row_gain: float = 10.0) -> Dict[str, np.ndarray]:
+    """"Realistic-outlier" weight profile: trained Whisper checkpoints carry a few very large LayerNorm gains and massive
+    residual channels.  Four channels of every LayerNorm weight are multiplied by `ln_gain`, two output rows of every fc2 /
+    out_proj weight by `row_gain`, everything else is left as is (no checkpoint exists offline: SURVEY.md section 8c).  Used by the
+    parity tests and by bench.py's `outlier_profile` block to show what each operand precision keeps of the absolute 1e-3 bound."""
+    W = dict(W)
+    rng = np.random.default_rng(seed)
+    for name in list(W):
+        if name.endswith("_layer_norm.weight") or name == "layer_norm.weight":
+            idx = rng.choice(cfg.d_model, 4, replace=False)
+            W[name] = W[name].copy(); W[name][idx] *= ln_gain
+        if name.endswith("fc2.weight") or name.endswith("out_proj.weight"):
+            idx = rng.choice(W[name].shape[0], 2, replace=False)
+            W[name] = W[name].copy(); W[name][idx] *= row_gain      # rows feeding outlier residual channels
+    return W

@@ -230,27 +230,23 @@ def test_every_gemm_tiling_gives_the_same_bits(precision):
             _lib.tuning_set("gemm_tile", 0)
 
 
-def test_outlier_channels_keep_the_relative_error():
-    """Trained Whisper weights have a few very large LayerNorm gains / activation channels.  The split-bf16 operands are
-    floating point per element (relative 2^-17), so outliers do not change the RELATIVE error (rel-L2 ~5e-5), but the
-    absolute error of a channel grows with the gains on its path: with 30x gains on every LayerNorm (outputs up to |x| ~ 66)
-    the worst element is off by ~7e-3, where the reference's own fp32 arithmetic is off by 7e-4 from fp64 on the same
-    weights.  DESIGN.md "Numerics" states the absolute 1e-3 bound with that scope."""
+# measured envelope per operand precision on the outlier profile (weights.with_outlier_channels: 30x LayerNorm gains, 10x fc2 /
+# out_proj rows; outputs reach |x| ~ 66): (rel-L2 bound, max-abs bound).  Errors are RELATIVE per product, so the absolute
+# error of a channel grows with the gains on its path; only the split-fp16 mode (2^-23 per operand) keeps the ABSOLUTE 1e-3
+# bound here -- at the level of the reference's own fp32 arithmetic, which is 7e-4 from fp64 on these weights.
+OUTLIER_TOL = {"bf16x3": (1e-4, 1.5e-2), "fp16x3": (2e-5, 1e-3), "f16f8": (3e-4, 5e-2)}
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "fp16x3", "f16f8"])
+def test_outlier_channels_keep_the_relative_error(precision):
     cfg = wts.config("tiny", True)
-    W = wts.init_encoder_weights(cfg, 0, "test")
-    rng = np.random.default_rng(0)
-    for name in list(W):
-        if name.endswith("_layer_norm.weight") or name == "layer_norm.weight":
-            idx = rng.choice(cfg.d_model, 4, replace=False)
-            W[name] = W[name].copy(); W[name][idx] *= 30.0
-        if name.endswith("fc2.weight") or name.endswith("out_proj.weight"):
-            idx = rng.choice(W[name].shape[0], 2, replace=False)
-            W[name] = W[name].copy(); W[name][idx] *= 10.0      # rows feeding outlier residual channels
+    W = wts.with_outlier_channels(wts.init_encoder_weights(cfg, 0, "test"), cfg, seed=0)
     mel = _mel(cfg, 2)
-    enc = _native(cfg, "bf16x3")
+    enc = _native(cfg, precision)
     enc.load_state_dict({k: torch.from_numpy(v) for k, v in W.items()})
     out = enc(torch.from_numpy(mel).cuda()).last_hidden_state.cpu().numpy()
     ref = oracle_enc.encoder_forward(W, mel, cfg.heads, dtype=torch.float64).numpy()
     e = oracle_enc.error_norms(out, ref)
+    print(precision, e)
     assert float(np.abs(ref).max()) > 30.0
-    assert e["rel_l2"] < 1e-4 and e["max_abs"] < 1.5e-2, e
+    assert e["rel_l2"] < OUTLIER_TOL[precision][0] and e["max_abs"] < OUTLIER_TOL[precision][1], e

@@ -11,12 +11,12 @@ from oracle import logmel as oracle_mel
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def full():
+@pytest.fixture(scope="module", params=["f16f8", "bf16x3"])      # the headline mode and the split-bf16 mode the training path uses
+def full(request):
     from mlx8_ws_audio_transformer_amd.encoder import NativeWhisperEncoder
     cfg = wts.config("small")
     pcm = torch.from_numpy(synth.synth_clips_i16(64, seed=1234, first=100)).cuda()
-    enc = NativeWhisperEncoder(cfg, precision="bf16x3", seed=0, init_profile="hf").eval()
+    enc = NativeWhisperEncoder(cfg, precision=request.param, seed=0, init_profile="hf").eval()
     hidden, feats = enc.encode_pcm(pcm, return_features=True)
     return cfg, pcm, enc, hidden, feats
 
@@ -37,7 +37,7 @@ def test_batch_permutation_and_chunking_are_exact(full):
     from mlx8_ws_audio_transformer_amd.encoder import NativeWhisperEncoder
     perm = torch.randperm(64, generator=torch.Generator().manual_seed(5)).cuda()
     assert torch.equal(enc.encode_pcm(pcm[perm].contiguous()), hidden[perm])        # clips are independent
-    small_chunks = NativeWhisperEncoder(cfg, precision="bf16x3", seed=0, init_profile="hf", chunk_clips=24).eval()
+    small_chunks = NativeWhisperEncoder(cfg, precision=enc.precision, seed=0, init_profile="hf", chunk_clips=24).eval()
     assert torch.equal(small_chunks.encode_pcm(pcm), hidden)                            # chunk size is invisible
 
 

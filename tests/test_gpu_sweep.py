@@ -20,7 +20,7 @@ def swept():
     host, first = sweep.stage_shard(N, 0, 1, seed=1234)
     assert first == 0 and host.shape == (N, 64000) and host.dtype == np.int16
     pcm = torch.from_numpy(host).cuda()
-    enc = NativeWhisperEncoder(cfg, precision="bf16x3", seed=0, init_profile="hf").eval()
+    enc = NativeWhisperEncoder(cfg, seed=0, init_profile="hf").eval()          # default precision (f16f8)
     out = torch.empty((N, cfg.max_source_positions, cfg.d_model), device="cuda")
     seen = []
 
