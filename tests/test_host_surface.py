@@ -76,3 +76,26 @@ def test_classifier_keeps_reference_parameter_names_and_refuses_to_train():
         nat.train()(torch.zeros(1, 80, 126))
     with pytest.raises(ValueError):
         TransformerUrbanSound8KClassifier(dim=128, heads=1)            # head_dim 128 > the kernel's 64
+
+
+# ---------------------------------------------------------------- a14: tokenizer stand-in of the transcribe / tester loop (host side)
+def test_note_tokenizer_roundtrip_and_collator_padding():
+    from mlx8_ws_audio_transformer_amd import synth
+    from mlx8_ws_audio_transformer_amd.collator import DataCollatorSpeechSeq2SeqWithPadding
+    from mlx8_ws_audio_transformer_amd.feature_extraction import WhisperProcessor
+    from mlx8_ws_audio_transformer_amd.transcribe import NoteTokenizer
+    tok = NoteTokenizer()
+    label = synth.clip_label(1234, 0)                       # "<|MIDI|> G#6 F2 ... <|/MIDI|>" like AB/synthDataset.py:82
+    ids = tok(label)["input_ids"]
+    assert ids[0] == tok.bos_token_id and ids[-1] == tok.eos_token_id and tok.unk_token_id not in ids
+    assert tok.decode(ids, skip_special_tokens=True) == label
+    assert tok.batch_decode([ids, ids[:4]], skip_special_tokens=True)[1] == " ".join(label.split()[:3])
+    both = tok([label, "<|MIDI|> C4 <|/MIDI|>"])["input_ids"]
+    assert len(both) == 2 and len(both[1]) == 5
+    proc = WhisperProcessor(tokenizer=tok)
+    assert proc(text=label)["labels"] == ids               # the processor's text branch (fineTune.py:88)
+    coll = DataCollatorSpeechSeq2SeqWithPadding(processor=proc, decoder_start_token_id=tok.bos_token_id)
+    feats = [{"input_features": np.zeros((80, 8), np.float32), "labels": both[0]}, {"input_features": np.zeros((80, 8), np.float32), "labels": both[1]}]
+    batch = coll(feats)
+    assert batch["labels"].shape == (2, len(both[0]) - 1)    # every row starts with BOS: the collator strips it (fineTune.py:114-115)
+    assert (batch["labels"][1, len(both[1]) - 1:] == -100).all()
