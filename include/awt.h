@@ -101,14 +101,18 @@ typedef struct awt_encoder_cfg {
   int32_t ffn_dim;          /* multiple of 128                                                             */
   int32_t n_mels;           /* 80 (tiny .. large-v2) or 128 (large-v3); multiple of 8, <= 128              */
   int32_t n_ctx;            /* S = max_source_positions: 1500 (reference) or 200 (trimmed); mel T = 2*S    */
-  int32_t mfma_terms;       /* 1: bf16 operands (fast; ~4e-3 rel-L2 vs fp32); 3: split-bf16 hi+lo operands,
-                               three MFMA products per fragment pair (meets the 1e-3 parity bound)         */
+  int32_t mfma_terms;       /* operand precision of the forward pass:
+                               1 bf16: one bf16 MFMA per fragment pair (fast; ~4e-3 rel-L2 vs fp32, misses the 1e-3 bound);
+                               3 bf16x3: split-bf16 hi + lo planes, three MFMAs (2^-17 per operand; the training format);
+                               4 fp16x3: split-fp16 planes, three MFMAs (2^-23 per operand; operands within fp16's range);
+                               5 f16f8: fp16 plane + two e4m3 planes, the two cross terms on the block-scaled fp8 MFMA: two
+                                 MFMA-equivalents per fragment pair (2^-16 per operand); inference only                  */
   int32_t lora_rank;        /* 0 = no adapters; else 1..64                                                 */
   float lora_alpha;         /* adapter scale = lora_alpha / lora_rank                                      */
   uint32_t lora_targets;    /* bit mask of AWT_LORA_*                                                      */
   int32_t chunk_clips;      /* clips processed per kernel wave (0 = library default)                       */
   int32_t training;         /* != 0: keep transposed copies of the frozen weights so awt_encoder_backward can run
-                               (adapters on q/k/v only in this mode)                                        */
+                               (mfma_terms 1 or 3 in this mode)                                             */
   int32_t backward_terms;   /* products of the backward pass' gradient contractions: 0 = mfma_terms (default: gradients
                                to 3e-5 of fp32 autograd), 1 with mfma_terms = 3 = one bf16 product (the usual
                                mixed-precision trade: ~0.5 % gradient error, 1.4x faster step); the attention scores are
@@ -143,8 +147,9 @@ int awt_encoder_forward(awt_encoder* e, const float* input_features, int B, int 
  * untouched until awt_encoder_backward has been enqueued on the same stream).
  * awt_encoder_backward takes d(loss)/d(last_hidden_state) [B, n_ctx, d_model] and writes the gradients of every
  * adapter into `lora_grads` (float32, awt_encoder_lora_grad_count(e) elements): for each layer in order, for each
- * enabled target in the order q, k, v: dA [r, d_model] then dB [d_model, r], row-major.  Gradients of frozen weights
- * and of the input features are not produced (nothing below the first adapter needs them). */
+ * enabled target in the order q_proj, k_proj, v_proj, out_proj, fc1, fc2: dA [r, in_features] then dB [out_features, r], row-major
+ * (in / out = d_model except fc1: out = ffn_dim, fc2: in = ffn_dim).  Gradients of frozen weights and of the input features are
+ * not produced (nothing below the first adapter needs them). */
 size_t awt_encoder_train_workspace_bytes(const awt_encoder* e, int B);
 size_t awt_encoder_lora_grad_count(const awt_encoder* e);
 int awt_encoder_forward_train(awt_encoder* e, const float* input_features, int B, int n_frames, float* last_hidden_state,
@@ -201,6 +206,53 @@ int awt_op_layernorm(awt_ctx* c, const float* x /*[M,d]*/, const float* gamma, c
 int awt_op_attention(awt_ctx* c, const float* q, const float* k, const float* v, float* o, int B, int H, int S,
                      int terms, void* workspace, size_t ws_bytes, void* stream);
 size_t awt_op_attention_workspace_bytes(int B, int H, int S);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Decoder-side operators of the fine-tune step (scope row "next" #1): what `WhisperForConditionalGeneration.forward` runs after
+ * the encoder -- /root/reference/AB/fineTune.py:131,186-199 -> HF:modeling_whisper.py:416-507 (decoder layer), :649-797
+ * (decoder), :994-1100 (shift labels, tied projection, cross-entropy).  B x L label tokens (L ~ 12, <= 448) against frozen
+ * weights: the linears are weight-bound GEMMs on the encoder's MFMA kernel over weights packed once (`awt_weight`); attention is
+ * an fp32 row kernel (causal self-attention, cross-attention over the 1500 encoder positions) that reads q / k / v in place from
+ * the row-major outputs of the linears.  All float32 in / out, row-major, caller-owned device memory, deterministic.
+ */
+typedef struct awt_weight awt_weight;
+/* Packs a frozen nn.Linear weight [N, K] (+ bias [N] or NULL) once: N is zero-padded to a multiple of 128 (awt_weight_padded_rows),
+ * K must be a multiple of 64; precision 1 (bf16) or 3 (bf16x3); with_transpose keeps the transposed copy that
+ * awt_linear_backward_input needs (then K must be a multiple of 128). */
+int awt_weight_create(awt_ctx* c, const float* w, const float* bias, int N, int K, int precision, int with_transpose, void* stream,
+                      awt_weight** out);
+void awt_weight_destroy(awt_weight* w);
+int awt_weight_padded_rows(const awt_weight* w);
+size_t awt_linear_workspace_bytes(const awt_weight* w, int M, int backward);   /* backward != 0: for awt_linear_backward_input */
+/* y [M, Np] = x [M, K] W^T + bias (+ resid [M, Np], may alias y)      F.linear / the residual adds of HF:modeling_whisper.py:468-500 */
+int awt_linear_forward(awt_ctx* c, const awt_weight* w, const float* x, const float* resid, float* y, int M, void* workspace,
+                       size_t ws_bytes, void* stream);
+/* dx [M, K] = dy [M, Np] W                                             (frozen weight: no weight gradient) */
+int awt_linear_backward_input(awt_ctx* c, const awt_weight* w, const float* dy, float* dx, int M, void* workspace, size_t ws_bytes,
+                              void* stream);
+/* x[m, :] = embed_tokens[ids[m], :] + embed_positions[pos0 + m % L, :]     HF:modeling_whisper.py:756-770 */
+int awt_op_embed(awt_ctx* c, const int64_t* ids, const float* tok, const float* pos, float* x, int M, int L, int d, int pos0, int vocab,
+                 void* stream);
+int awt_op_gelu(awt_ctx* c, const float* x, float* y, int64_t n, void* stream);                          /* exact erf GELU */
+int awt_op_gelu_backward(awt_ctx* c, const float* x, const float* dy, float* dx, int64_t n, void* stream);
+/* dx = dres + d(LayerNorm(x) * gamma + beta)/dx . dy   (frozen affine: no dgamma / dbeta; dres NULL or the gradient arriving over the
+ * residual connection; dx may alias dres) */
+int awt_op_layernorm_backward(awt_ctx* c, const float* dy, const float* x, const float* gamma, const float* dres, float* dx, int M, int d,
+                              float eps, void* stream);
+/* CrossEntropyLoss(ignore_index = -100, mean) over the first `vocab` of `ld` columns: *loss and d(loss)/d(logits) [M, ld]
+ * (padding columns zero).  scratch: (M + 1) * 4 bytes.                    HF:modeling_whisper.py:1079-1086 */
+int awt_op_cross_entropy(awt_ctx* c, const float* logits, const int64_t* labels, int M, int vocab, int ld, float* loss, float* dlogits,
+                         void* scratch, void* stream);
+/* softmax(0.125 q k^T [+ causal mask]) v for head_dim 64 with few query rows.  Row (b, i) of q at q + (b Lq + i) ldq + 64 h; row
+ * (b, j) of k / v at k + (b Sk + j) ldk + 64 h; o like q with ldo.  causal != 0: key j is visible to query i iff
+ * j <= i + causal_off (causal_off = Sk - Lq for cached decoding).  lse [B, H, Lq] (optional) feeds the backward pass.
+ * HF:modeling_whisper.py:215-238, 284-356 (q scaled by head_dim^-1/2; eager attention with the causal mask). */
+int awt_op_attention_small(awt_ctx* c, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo,
+                           float* lse, int B, int H, int Lq, int Sk, int causal, int causal_off, void* stream);
+/* dq (layout of q), dk / dv (layout of k / v: every element of the B x Sk x H x 64 blocks is written); delta [B, H, Lq] scratch */
+int awt_op_attention_small_backward(awt_ctx* c, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o,
+                                    const float* dout, int ldo, const float* lse, float* delta, float* dq, float* dk, float* dv, int B,
+                                    int H, int Lq, int Sk, int causal, int causal_off, void* stream);
 
 /* Process-wide tuning / test hooks (no effect on results).  key "gemm_tile": 0 = choose the GEMM block tile from the
  * shape (default), 64 / 128 / 256 = force the 64 x 128, 128 x 128 or 128 x 256 tile (256 falls back to 128 when N is not

@@ -73,6 +73,19 @@ _SIGNATURES = {
     "awt_op_layernorm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "awt_op_attention": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "awt_op_attention_workspace_bytes": (_sz, [_i, _i, _i]),
+    "awt_weight_create": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, C.POINTER(_vp)]),
+    "awt_weight_destroy": (None, [_vp]),
+    "awt_weight_padded_rows": (_i, [_vp]),
+    "awt_linear_workspace_bytes": (_sz, [_vp, _i, _i]),
+    "awt_linear_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
+    "awt_linear_backward_input": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
+    "awt_op_embed": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "awt_op_gelu": (_i, [_vp, _vp, _vp, _i64, _vp]),
+    "awt_op_gelu_backward": (_i, [_vp, _vp, _vp, _vp, _i64, _vp]),
+    "awt_op_layernorm_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    "awt_op_cross_entropy": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "awt_op_attention_small": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "awt_op_attention_small_backward": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "awt_tuning_set": (_i, [C.c_char_p, _i]),
     "awt_prof_enable": (_i, [_vp, _i]),
     "awt_prof_collect": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(C.c_double)]),

@@ -306,6 +306,7 @@ int linear_with_lora(awt_encoder* e, bf16_t* const u[2], bf16_t* const in[2], in
 struct LayerBufs {
   float *x_in, *x_mid, *x_out;            // residual stream before the layer, after attention, after the MLP
   bf16_t *ln1[2], *qkv[2], *att[2], *ln2[2], *pre[2], *ff[2], *u[2];
+  bf16_t *uo[2], *u1[2], *u2[2];          // u = (alpha / r) x A^T of the out_proj / fc1 / fc2 adapters (inference: alias u; training: kept)
   float* lse;                             // [B, H, S] or null
 };
 
@@ -337,6 +338,10 @@ TrainWs carve_train(const awt_encoder* e, char* base, int B) {
     x = L.x_out;
     planes(L.ln1, M * d); planes(L.qkv, 3 * M * d); planes(L.att, M * d); planes(L.ln2, M * d); planes(L.pre, M * f);
     planes(L.u, M * 128);
+    const bool has_o = e->layers[li].lo_.active, has_1 = e->layers[li].l1.active, has_2 = e->layers[li].l2.active;
+    if (has_o) planes(L.uo, M * 128); else { L.uo[0] = L.u[0]; L.uo[1] = L.u[1]; }
+    if (has_1) planes(L.u1, M * 128); else { L.u1[0] = L.u[0]; L.u1[1] = L.u[1]; }
+    if (has_2) { planes(L.u2, M * 128); planes(L.ff, M * f); } else { L.u2[0] = L.u[0]; L.u2[1] = L.u[1]; L.ff[0] = L.ff[1] = nullptr; }
     L.lse = (float*)take((size_t)B * H * S * 4);
   }
   w.x_final = x;
@@ -349,10 +354,10 @@ TrainWs carve_train(const awt_encoder* e, char* base, int B) {
   w.dx_a = (float*)take(M * d * 4); w.dx_b = (float*)take(M * d * 4); w.dln = (float*)take(M * d * 4);
   w.delta = (float*)take((size_t)B * H * S * 4);
   planes(w.dxp, M * d); planes(w.dpre, M * f); planes(w.datt, M * d); planes(w.dqkv, 3 * M * d); planes(w.du, M * 128);
-  w.partial_bytes = outer_reduce_partial_bytes((int)M, c.lora_rank > 0 ? c.lora_rank : 1, (int)d);
+  w.partial_bytes = outer_reduce_partial_bytes((int)M, c.lora_rank > 0 ? c.lora_rank : 1, 1024);   // Y blocks are reduced in chunks of <= 1024 columns
   w.partial = (float*)take(w.partial_bytes);
   w.bytes = std::max(off, conv_end);
-  for (int li = 0; li < c.n_layers; ++li) for (int p = 0; p < 2; ++p) w.layer[li].ff[p] = w.ff[p];
+  for (int li = 0; li < c.n_layers; ++li) for (int p = 0; p < 2; ++p) if (!w.layer[li].ff[p]) w.layer[li].ff[p] = w.ff[p];   // kept per layer only under an fc2 adapter
   return w;
 }
 
@@ -402,15 +407,15 @@ int encoder_layer(awt_encoder* e, Layer& L, const LayerBufs& b, int Bc, bool sav
   if (rc) return rc;
   {
     GemmOut o{}; o.f32 = b.x_mid; o.resid = b.x_in; o.ldo = d;
-    rc = linear_with_lora(e, b.u, b.att, d, L.out, L.lo_, M, EPI_F32_RESID, o, s); if (rc) return rc;
+    rc = linear_with_lora(e, b.uo, b.att, d, L.out, L.lo_, M, EPI_F32_RESID, o, s); if (rc) return rc;
   }
   rc = launch_layernorm(e->ctx, b.x_mid, L.ln2_g, L.ln2_b, M, d, 1e-5f, nullptr, make_act(b.ln2[0], b.ln2[1], (size_t)plane, terms), terms, s); if (rc) return rc;
   {
     GemmOut o{}; set_out(o, make_act(b.ff[0], b.ff[1], (size_t)M * f, terms)); o.ldo = f; o.hi2 = b.pre[0]; o.lo2 = b.pre[1];
-    rc = linear_with_lora(e, b.u, b.ln2, d, L.fc1, L.l1, M, save ? EPI_BF16_GELU_SAVE : EPI_BF16_GELU, o, s); if (rc) return rc;
+    rc = linear_with_lora(e, b.u1, b.ln2, d, L.fc1, L.l1, M, save ? EPI_BF16_GELU_SAVE : EPI_BF16_GELU, o, s); if (rc) return rc;
   }
   GemmOut o{}; o.f32 = b.x_out; o.resid = b.x_mid; o.ldo = d;
-  return linear_with_lora(e, b.u, b.ff, f, L.fc2, L.l2, M, EPI_F32_RESID, o, s);
+  return linear_with_lora(e, b.u2, b.ff, f, L.fc2, L.l2, M, EPI_F32_RESID, o, s);
 }
 
 int forward_chunk(awt_encoder* e, const float* mel, int Bc, float* hidden, char* ws_base, hipStream_t s) {
@@ -426,7 +431,7 @@ int forward_chunk(awt_encoder* e, const float* mel, int Bc, float* hidden, char*
   for (int p = 0; p < 2; ++p) {
     const bool on = p == 0 || two;
     b.ln1[p] = b.ln2[p] = on ? w.ln[p] : nullptr; b.qkv[p] = on ? w.qkv[p] : nullptr; b.att[p] = on ? w.att[p] : nullptr;
-    b.ff[p] = on ? w.ff[p] : nullptr; b.u[p] = on ? w.u[p] : nullptr; b.pre[p] = nullptr;
+    b.ff[p] = on ? w.ff[p] : nullptr; b.u[p] = b.uo[p] = b.u1[p] = b.u2[p] = on ? w.u[p] : nullptr; b.pre[p] = nullptr;
   }
   for (int li = 0; li < c.n_layers; ++li) { rc = encoder_layer(e, e->layers[li], b, Bc, false, s); if (rc) return rc; }
   return launch_layernorm(e->ctx, w.x, e->lnf_g, e->lnf_b, M, d, 1e-5f, hidden, Act{}, e->prec, s);
@@ -478,8 +483,7 @@ extern "C" int awt_encoder_create(awt_ctx* c, const awt_encoder_cfg* cfg, awt_en
               "encoder_create: backward_terms must be 0 (= mfma_terms), mfma_terms, or 1");
   AWT_REQUIRE(cfg->lora_rank >= 0 && cfg->lora_rank <= 32, AWT_ERR_INVALID, "encoder_create: lora_rank must be in 0..32");
   AWT_REQUIRE(cfg->lora_rank == 0 || cfg->lora_targets != 0, AWT_ERR_INVALID, "encoder_create: lora_rank > 0 needs lora_targets");
-  AWT_REQUIRE(!cfg->training || (cfg->lora_rank > 0 && !(cfg->lora_targets & (AWT_LORA_OUT | AWT_LORA_FC1 | AWT_LORA_FC2))), AWT_ERR_INVALID,
-              "encoder_create: training mode needs adapters, and supports them on q_proj / k_proj / v_proj only");
+  AWT_REQUIRE(!cfg->training || cfg->lora_rank > 0, AWT_ERR_INVALID, "encoder_create: training mode needs adapters (lora_rank > 0)");
   awt_encoder* e = new awt_encoder();
   e->ctx = c; e->cfg = *cfg; e->prec = cfg->mfma_terms; e->planes = cfg->mfma_terms == PREC_BF16 ? 1 : 2;
   e->chunk = cfg->chunk_clips > 0 ? cfg->chunk_clips : 64;
@@ -720,11 +724,21 @@ extern "C" size_t awt_encoder_train_workspace_bytes(const awt_encoder* e, int B)
   return carve_train(e, nullptr, B).bytes;
 }
 
+namespace {
+// elements of one layer's adapter gradients: for every enabled target in the order q, k, v, out, fc1, fc2: dA [r, K_in] then dB [N_out, r]
+size_t lora_grads_per_layer(const awt_encoder_cfg& c) {
+  const size_t r = c.lora_rank, d = c.d_model, f = c.ffn_dim;
+  size_t n = 0;
+  for (uint32_t bit : {AWT_LORA_Q, AWT_LORA_K, AWT_LORA_V, AWT_LORA_OUT}) if (c.lora_targets & bit) n += 2 * r * d;
+  if (c.lora_targets & AWT_LORA_FC1) n += r * d + f * r;
+  if (c.lora_targets & AWT_LORA_FC2) n += r * f + d * r;
+  return n;
+}
+}  // namespace
+
 extern "C" size_t awt_encoder_lora_grad_count(const awt_encoder* e) {
   if (!e || e->cfg.lora_rank <= 0) return 0;
-  size_t slots = 0;
-  for (uint32_t bit : {AWT_LORA_Q, AWT_LORA_K, AWT_LORA_V}) if (e->cfg.lora_targets & bit) ++slots;
-  return (size_t)e->cfg.n_layers * slots * 2 * (size_t)e->cfg.lora_rank * e->cfg.d_model;
+  return (size_t)e->cfg.n_layers * lora_grads_per_layer(e->cfg);
 }
 
 extern "C" int awt_encoder_forward_train(awt_encoder* e, const float* mel, int B, int n_frames, float* hidden, void* saved,
@@ -778,61 +792,85 @@ extern "C" int awt_encoder_backward_ex(awt_encoder* e, const float* d_hidden, in
   const int64_t plane = (int64_t)M * d;
   const float lscale = c.lora_alpha / (float)r;
   TrainWs w = carve_train(e, (char*)saved, B);
-  const uint32_t bits[3] = {AWT_LORA_Q, AWT_LORA_K, AWT_LORA_V};
-  int nslots = 0;
-  for (uint32_t bit : bits) if (c.lora_targets & bit) ++nslots;
-  const size_t per_layer = (size_t)nslots * 2 * r * d;
+  const size_t per_layer = lora_grads_per_layer(c);
+  int rc;
+
+  // One adapter group (adapters that share an input): du = dy B into w.du, then per adapter dA = lscale du^T x_in and dB = dy^T u at
+  // `gp` (advanced).  Forward: u = lscale x_in A^T (saved), y = x_in W^T + b + u B^T.  The group's du stays in w.du for the caller's
+  // dX product, which takes it as a second K-segment against (lscale A)^T.
+  struct Slot { uint32_t bit; int col; int n_out; };
+  auto group_backward = [&](LoraGroup& lg, const bf16_t* dy0, const bf16_t* dy1, int ld_dy, int n_out_total, const Slot* slots, int nslot, bf16_t* const xin[2],
+                            int k_in, bf16_t* const u[2], float*& gp) -> int {
+    if (!lg.active) return AWT_OK;
+    {
+      GemmSeg sg = seg_plain(dy0, dy1, ld_dy, lg.bT, 0, n_out_total, M);
+      GemmOut o{}; o.hi = w.du[0]; o.lo = w.du[1]; o.ldo = lg.kp; o.n_valid = lg.kp; o.scale = 1.0f;
+      int rc2 = launch_gemm(e->ctx, M, 128, &sg, 1, gterms, EPI_BF16, o, s); if (rc2) return rc2;
+    }
+    for (int i = 0; i < nslot; ++i) {          // adapter i of the group owns rows / columns i r .. i r + r - 1 of A / B, u and du (set_weight)
+      if (!(c.lora_targets & slots[i].bit)) continue;
+      float* dA = gp;
+      float* dB = dA + (size_t)r * k_in;
+      int rc2 = launch_outer_reduce(e->ctx, w.du[0], w.du[1], lg.kp, i * r, r, xin[0], xin[1], k_in, 0, k_in, M, lscale, dA, k_in, 1,
+                                    w.partial, w.partial_bytes, accumulate, s);
+      if (rc2) return rc2;
+      rc2 = launch_outer_reduce(e->ctx, u[0], u[1], lg.kp, i * r, r, dy0, dy1, ld_dy, slots[i].col, slots[i].n_out, M, 1.0f, dB, 1, r,
+                                w.partial, w.partial_bytes, accumulate, s);
+      if (rc2) return rc2;
+      gp = dB + (size_t)slots[i].n_out * r;
+    }
+    return AWT_OK;
+  };
+  // slot order inside a group follows the order the forward packs A rows / B columns: the enabled targets of the group, in order
+  const Slot qkv_slots[3] = {{AWT_LORA_Q, 0, d}, {AWT_LORA_K, d, d}, {AWT_LORA_V, 2 * d, d}};
+  const Slot out_slot[1] = {{AWT_LORA_OUT, 0, d}}, fc1_slot[1] = {{AWT_LORA_FC1, 0, f}}, fc2_slot[1] = {{AWT_LORA_FC2, 0, d}};
 
   // final LayerNorm
   float* dx = w.dx_a; float* dx_other = w.dx_b;
-  int rc = launch_layernorm_bwd(e->ctx, d_hidden, w.x_final, e->lnf_g, nullptr, M, d, 1e-5f, dx, w.dxp[0], w.dxp[1], s); if (rc) return rc;
+  rc = launch_layernorm_bwd(e->ctx, d_hidden, w.x_final, e->lnf_g, nullptr, M, d, 1e-5f, dx, w.dxp[0], w.dxp[1], s); if (rc) return rc;
   for (int li = c.n_layers - 1; li >= 0; --li) {
     Layer& L = e->layers[li];
     const LayerBufs& b = w.layer[li];
-    // ---- MLP: dpre = (dx W2) * gelu'(pre) ; dln = dpre W1 ; dx_mid = dx + LN2_bwd(dln)
+    // gradient layout of the layer: q, k, v, out, fc1, fc2 (enabled ones); the groups are visited fc2, fc1, out, qkv
+    float* g_qkv = lora_grads + (size_t)li * per_layer;
+    size_t n_qkv = 0;
+    for (const Slot& sl : qkv_slots) if (c.lora_targets & sl.bit) n_qkv += (size_t)2 * r * d;
+    float* g_out = g_qkv + n_qkv;
+    float* g_fc1 = g_out + ((c.lora_targets & AWT_LORA_OUT) ? (size_t)2 * r * d : 0);
+    float* g_fc2 = g_fc1 + ((c.lora_targets & AWT_LORA_FC1) ? (size_t)r * d + (size_t)f * r : 0);
+    // ---- MLP: dpre = ([dx | du2] [W2 | lscale A2]) * gelu'(pre) ; dln = [dpre | du1] [W1 | lscale A1] ; dx_mid = dx + LN2_bwd(dln)
+    rc = group_backward(L.l2, w.dxp[0], w.dxp[1], d, d, fc2_slot, 1, b.ff, f, b.u2, g_fc2); if (rc) return rc;
     {
-      GemmSeg sg = seg_plain(w.dxp[0], w.dxp[1], d, L.fc2T, 0, d, M);
+      GemmSeg sg[2];
+      sg[0] = seg_plain(w.dxp[0], w.dxp[1], d, L.fc2T, 0, d, M);
+      if (L.l2.active) sg[1] = seg_plain(w.du[0], w.du[1], L.l2.kp, L.l2.aT, 0, L.l2.kp, M);
       GemmOut o{}; o.hi = w.dpre[0]; o.lo = w.dpre[1]; o.ldo = f; o.n_valid = f; o.pre_hi = b.pre[0]; o.pre_lo = b.pre[1];
-      rc = launch_gemm(e->ctx, M, f, &sg, 1, gterms, EPI_BF16_DGELU, o, s); if (rc) return rc;
+      rc = launch_gemm(e->ctx, M, f, sg, L.l2.active ? 2 : 1, gterms, EPI_BF16_DGELU, o, s); if (rc) return rc;
     }
+    rc = group_backward(L.l1, w.dpre[0], w.dpre[1], f, f, fc1_slot, 1, b.ln2, d, b.u1, g_fc1); if (rc) return rc;
     {
-      GemmSeg sg = seg_plain(w.dpre[0], w.dpre[1], f, L.fc1T, 0, f, M);
+      GemmSeg sg[2];
+      sg[0] = seg_plain(w.dpre[0], w.dpre[1], f, L.fc1T, 0, f, M);
+      if (L.l1.active) sg[1] = seg_plain(w.du[0], w.du[1], L.l1.kp, L.l1.aT, 0, L.l1.kp, M);
       GemmOut o{}; o.f32 = w.dln; o.ldo = d; o.n_valid = d;
-      rc = launch_gemm(e->ctx, M, d, &sg, 1, gterms, EPI_F32, o, s); if (rc) return rc;
+      rc = launch_gemm(e->ctx, M, d, sg, L.l1.active ? 2 : 1, gterms, EPI_F32, o, s); if (rc) return rc;
     }
     rc = launch_layernorm_bwd(e->ctx, w.dln, b.x_mid, L.ln2_g, dx, M, d, 1e-5f, dx_other, w.dxp[0], w.dxp[1], s); if (rc) return rc;
     std::swap(dx, dx_other);   // dx = d(loss)/d(x_mid)
-    // ---- attention: datt = dx_mid Wo ; (dq, dk, dv) = attention_bwd
+    // ---- attention: datt = [dx_mid | duo] [Wo | lscale Ao] ; (dq, dk, dv) = attention_bwd
+    rc = group_backward(L.lo_, w.dxp[0], w.dxp[1], d, d, out_slot, 1, b.att, d, b.uo, g_out); if (rc) return rc;
     {
-      GemmSeg sg = seg_plain(w.dxp[0], w.dxp[1], d, L.outT, 0, d, M);
+      GemmSeg sg[2];
+      sg[0] = seg_plain(w.dxp[0], w.dxp[1], d, L.outT, 0, d, M);
+      if (L.lo_.active) sg[1] = seg_plain(w.du[0], w.du[1], L.lo_.kp, L.lo_.aT, 0, L.lo_.kp, M);
       GemmOut o{}; o.hi = w.datt[0]; o.lo = w.datt[1]; o.ldo = d; o.n_valid = d; o.scale = 1.0f;
-      rc = launch_gemm(e->ctx, M, d, &sg, 1, gterms, EPI_BF16, o, s); if (rc) return rc;
+      rc = launch_gemm(e->ctx, M, d, sg, L.lo_.active ? 2 : 1, gterms, EPI_BF16, o, s); if (rc) return rc;
     }
     rc = launch_attention_bwd(e->ctx, b.qkv[0], b.qkv[1], b.qkv[0] + plane, b.qkv[1] ? b.qkv[1] + plane : nullptr, b.qkv[0] + 2 * plane,
                               b.qkv[1] ? b.qkv[1] + 2 * plane : nullptr, b.att[0], b.att[1], w.datt[0], w.datt[1], b.lse, w.delta,
                               w.dqkv[0], w.dqkv[1], B, H, S, 0.125f, terms, gterms, s);
     if (rc) return rc;
-    // ---- adapter gradients.  Forward: u = lscale * ln1 A^T (saved), y = ln1 W^T + b + u B^T.
-    //      dB = dy^T u ; du = dy B ; dA = lscale * du^T ln1
-    {
-      GemmSeg sg = seg_plain(w.dqkv[0], w.dqkv[1], 3 * d, L.lq.bT, 0, 3 * d, M);
-      GemmOut o{}; o.hi = w.du[0]; o.lo = w.du[1]; o.ldo = L.lq.kp; o.n_valid = L.lq.kp; o.scale = 1.0f;
-      rc = launch_gemm(e->ctx, M, 128, &sg, 1, gterms, EPI_BF16, o, s); if (rc) return rc;
-    }
-    float* g = lora_grads + (size_t)li * per_layer;
-    int slot_out = 0;
-    for (int which = 0; which < 3; ++which) {
-      if (!(c.lora_targets & bits[which])) continue;
-      float* dA = g + (size_t)slot_out * 2 * r * d;
-      float* dB = dA + (size_t)r * d;
-      rc = launch_outer_reduce(e->ctx, w.du[0], w.du[1], L.lq.kp, which * r, r, b.ln1[0], b.ln1[1], d, 0, d, M, lscale, dA, d, 1,
-                               w.partial, w.partial_bytes, accumulate, s);
-      if (rc) return rc;
-      rc = launch_outer_reduce(e->ctx, b.u[0], b.u[1], L.lq.kp, which * r, r, w.dqkv[0], w.dqkv[1], 3 * d, which * d, d, M, 1.0f, dB, 1, r,
-                               w.partial, w.partial_bytes, accumulate, s);
-      if (rc) return rc;
-      ++slot_out;
-    }
+    rc = group_backward(L.lq, w.dqkv[0], w.dqkv[1], 3 * d, 3 * d, qkv_slots, 3, b.ln1, d, b.u, g_qkv); if (rc) return rc;
     // ---- gradient exchange: layers [li, group_hi) are final -- average them over the ranks on the side stream while the
     //      lower layers' backward continues on `s`
     if (exchange) {
@@ -850,9 +888,9 @@ extern "C" int awt_encoder_backward_ex(awt_encoder* e, const float* d_hidden, in
     {
       GemmSeg sg[2];
       sg[0] = seg_plain(w.dqkv[0], w.dqkv[1], 3 * d, L.qkvT, 0, 3 * d, M);
-      sg[1] = seg_plain(w.du[0], w.du[1], L.lq.kp, L.lq.aT, 0, L.lq.kp, M);
+      if (L.lq.active) sg[1] = seg_plain(w.du[0], w.du[1], L.lq.kp, L.lq.aT, 0, L.lq.kp, M);
       GemmOut o{}; o.f32 = w.dln; o.ldo = d; o.n_valid = d;
-      rc = launch_gemm(e->ctx, M, d, sg, 2, gterms, EPI_F32, o, s); if (rc) return rc;
+      rc = launch_gemm(e->ctx, M, d, sg, L.lq.active ? 2 : 1, gterms, EPI_F32, o, s); if (rc) return rc;
     }
     rc = launch_layernorm_bwd(e->ctx, w.dln, b.x_in, L.ln1_g, dx, M, d, 1e-5f, dx_other, w.dxp[0], w.dxp[1], s); if (rc) return rc;
     std::swap(dx, dx_other);

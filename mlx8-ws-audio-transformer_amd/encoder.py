@@ -127,8 +127,8 @@ class NativeWhisperEncoder(nn.Module):
             raise ValueError("the native attention kernel is specialised for head_dim 64 (every Whisper size)")
         if trainable and precision not in ("bf16", "bf16x3"):
             raise ValueError("trainable=True keeps its activations as bf16 planes: precision must be 'bf16x3' or 'bf16'")
-        if trainable and (lora is None or not set(lora.targets) <= {"q_proj", "k_proj", "v_proj"}):
-            raise ValueError("trainable=True needs LoRA adapters, on q_proj / k_proj / v_proj only")
+        if trainable and lora is None:
+            raise ValueError("trainable=True needs LoRA adapters")
         self.cfg = cfg
         self.precision = precision
         self.lora = lora
@@ -209,12 +209,13 @@ class NativeWhisperEncoder(nn.Module):
     # ------------------------------------------------------------------------------------------------ gradients
     def lora_parameters_library_order(self) -> list:
         """Adapter parameters in the order awt_encoder_backward lays their gradients out: per layer, per target in
-        (q_proj, k_proj, v_proj) order: lora_A then lora_B (include/awt.h)."""
-        order = [t for t in ("q_proj", "k_proj", "v_proj") if self.lora is not None and t in self.lora.targets]
+        (q_proj, k_proj, v_proj, out_proj, fc1, fc2) order: lora_A then lora_B (include/awt.h)."""
+        order = [t for t in ("q_proj", "k_proj", "v_proj", "out_proj", "fc1", "fc2") if self.lora is not None and t in self.lora.targets]
         params = []
         for i in range(self.cfg.layers):
+            layer = getattr(self.layers, str(i))
             for t in order:
-                leaf = getattr(getattr(getattr(self.layers, str(i)), "self_attn"), t)
+                leaf = getattr(layer, t) if t in ("fc1", "fc2") else getattr(getattr(layer, "self_attn"), t)
                 params += [leaf.lora_A, leaf.lora_B]
         return params
 

@@ -155,8 +155,11 @@ class WhisperLoRAModel(nn.Module):
 
     def __init__(self, cfg: EncoderConfig, lora: LoraSpec, precision: str = "bf16x3", device: str = "cuda", decoder_layers: Optional[int] = None,
                  seed: int = 0, vocab: int = WHISPER_VOCAB, decoder_autocast: Optional[torch.dtype] = None, native_cross_kv: bool = True,
-                 max_target_positions: int = 448, backward_precision: Optional[str] = None):
+                 max_target_positions: int = 448, backward_precision: Optional[str] = None, native_decoder: bool = False):
         super().__init__()
+        # native_decoder=True: decoder, tied projection and cross-entropy run on libawt as well (native_decoder.NativeWhisperDecoder,
+        # scope row f1); False keeps the stock-PyTorch decoder (pinned to HF by tests/golden/decoder.npz) around the native encoder
+        self.native_decoder = native_decoder
         # the decoder is stock PyTorch (scope row "next"): fp32 like the reference (fp16=False, fineTune.py:170) unless
         # decoder_autocast=torch.bfloat16 asks torch to run its matmuls in bf16
         self.decoder_autocast = decoder_autocast
@@ -166,6 +169,12 @@ class WhisperLoRAModel(nn.Module):
                                             backward_precision=backward_precision)
         torch.manual_seed(seed)
         self.decoder = WhisperDecoder(cfg.d_model, decoder_layers or cfg.layers, cfg.heads, cfg.ffn, vocab, max_target_positions).to(device)
+        if native_decoder:
+            from .native_decoder import NativeWhisperDecoder
+            nd = NativeWhisperDecoder(cfg.d_model, decoder_layers or cfg.layers, cfg.heads, cfg.ffn, vocab, max_target_positions,
+                                      precision=precision if precision in ("bf16", "bf16x3") else "bf16x3").to(device)
+            nd.load_state_dict(self.decoder.state_dict())       # the same initial weights as the torch decoder of this seed
+            self.decoder = nd
         for p in self.decoder.parameters():
             p.requires_grad = False             # frozen base model: only the adapters train
         self.config = SimpleNamespace(decoder_start_token_id=DECODER_START, pad_token_id=PAD_ID, eos_token_id=EOS_ID, d_model=cfg.d_model)
@@ -179,6 +188,12 @@ class WhisperLoRAModel(nn.Module):
                 raise ValueError("either labels or decoder_input_ids is required")
             decoder_input_ids = shift_tokens_right(labels, self.config.pad_token_id, self.config.decoder_start_token_id)
         hidden = self.encoder(input_features).last_hidden_state
+        if self.native_decoder:
+            if labels is not None:
+                loss, logits = self.decoder.loss(decoder_input_ids.to(hidden.device), labels.to(hidden.device), hidden)
+            else:
+                loss, logits = None, self.decoder(decoder_input_ids.to(hidden.device), hidden)
+            return SimpleNamespace(loss=loss, logits=logits, encoder_last_hidden_state=hidden)
         with torch.autocast("cuda", dtype=self.decoder_autocast or torch.bfloat16, enabled=self.decoder_autocast is not None):
             logits = self.decoder(decoder_input_ids.to(hidden.device), hidden, self.precision if self.native_cross_kv else None)
         loss = None
@@ -194,7 +209,7 @@ class WhisperLoRAModel(nn.Module):
         projection), then one token per step with a self-attention cache.  Returns [B, <= max_length] token ids, starting
         with decoder_start_token_id; rows that have emitted `eos_token_id` are padded with pad_token_id."""
         hidden = self.encoder(input_features).last_hidden_state
-        cross = self.decoder.cross_kv(hidden, self.precision) if self.native_cross_kv else None
+        cross = self.decoder.cross_kv(hidden, self.precision) if (self.native_cross_kv or self.native_decoder) else None
         with torch.autocast("cuda", dtype=self.decoder_autocast or torch.bfloat16, enabled=self.decoder_autocast is not None):
             return greedy_decode(self.decoder, hidden, self.config.decoder_start_token_id, self.config.pad_token_id,
                                  self.config.eos_token_id if eos_token_id is None else eos_token_id, max_length, cross=cross,

@@ -20,7 +20,12 @@ def _oracle_grads(W, LW, mel, cfg, spec, dout):
     return out.detach().numpy(), {k: v.grad.numpy() for k, v in Lt.items()}
 
 
+ALL = ("q_proj", "k_proj", "v_proj", "out_proj", "fc1", "fc2")
+
+
 @pytest.mark.parametrize("name,trimmed,targets,r", [("mini", True, ("q_proj", "v_proj"), 8), ("tiny", True, ("q_proj", "k_proj", "v_proj"), 16),
+                                                    # adapters on every encoder linear, and groups without the q/k/v group
+                                                    ("mini", True, ALL, 8), ("tiny", True, ALL, 16), ("mini", True, ("out_proj", "fc2"), 8), ("mini", False, ("v_proj", "fc1"), 4),
                                                     ("mini", False, ("q_proj", "v_proj"), 8),
                                                     # BASELINE.json configs[2] / [3] at full size: Whisper-small (d = 768, 12 layers), parity
                                                     # mode S = 1500, adapters on q_proj, v_proj, r = 8 and r = 16 (oracle autograd: ~20 s of CPU)
@@ -58,12 +63,14 @@ def test_lora_gradients_match_oracle_autograd(name, trimmed, targets, r):
     print("worst relative gradient error", worst)
 
 
-def test_backward_is_reproducible_and_rejects_unsupported_targets():
+def test_backward_is_reproducible_and_rejects_untrainable_configurations():
     from mlx8_ws_audio_transformer_amd.encoder import NativeWhisperEncoder
     cfg = wts.config("mini", True)
     with pytest.raises(ValueError):
-        NativeWhisperEncoder(cfg, lora=wts.LoraSpec(targets=("fc1",)), trainable=True)
-    spec = wts.LoraSpec(r=8, alpha=16.0)
+        NativeWhisperEncoder(cfg, trainable=True)                                   # no adapters: nothing to train
+    with pytest.raises(ValueError):
+        NativeWhisperEncoder(cfg, lora=wts.LoraSpec(), trainable=True, precision="f16f8")   # training keeps bf16 planes
+    spec = wts.LoraSpec(r=8, alpha=16.0, targets=ALL)
     enc = NativeWhisperEncoder(cfg, precision="bf16x3", lora=spec, trainable=True, seed=0, init_profile="test")
     enc.load_state_dict({k: torch.from_numpy(v) for k, v in {**wts.init_encoder_weights(cfg, 0, "test"),
                                                               **wts.init_lora_weights(cfg, spec, 0, zero_b=False)}.items()})

@@ -1,0 +1,145 @@
+"""GPU: the decoder-side operators (include/awt.h "Decoder-side operators", scope row f1) against torch autograd, and the native
+decoder + loss against `WhisperForConditionalGeneration` vectors (tests/golden/decoder.npz) and against the torch decoder's gradients."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from mlx8_ws_audio_transformer_amd import weights as wts
+from oracle import logmel as oracle_mel
+from tests.util import golden, piano_clips_f32
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).cuda()
+
+
+@pytest.mark.parametrize("M,N,K", [(12, 256, 128), (768, 1000, 768), (40, 768, 3072)])
+def test_packed_linear_forward_and_backward_input(M, N, K):
+    from mlx8_ws_audio_transformer_amd.native_decoder import PackedLinear
+    x, w, b, r = _rand((M, K), 1), _rand((N, K), 2, K ** -0.5), _rand((N,), 3), _rand((M, N), 4)
+    pl = PackedLinear(w, b)
+    Np = pl.Np
+    assert Np % 128 == 0 and Np >= N
+    y = pl.forward(x)
+    ref = F.linear(x.double(), w.double(), b.double())
+    assert (y[:, :N].double() - ref).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item())
+    assert float(y[:, N:].abs().max()) == 0.0 if Np > N else True
+    rp = F.pad(r, (0, Np - N))
+    y2 = pl.forward(x, resid=rp)
+    assert (y2[:, :N].double() - (ref + r.double())).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item())
+    dy = F.pad(_rand((M, N), 5), (0, Np - N))
+    dx = pl.backward_input(dy.contiguous())
+    dref = dy[:, :N].double() @ w.double()
+    assert (dx.double() - dref).abs().max().item() < 3e-5 * max(1.0, dref.abs().max().item())
+
+
+@pytest.mark.parametrize("B,H,Lq,Sk,causal,off", [(2, 2, 12, 12, True, 0), (3, 4, 7, 1500, False, 0), (2, 2, 1, 9, True, 8), (1, 2, 130, 130, True, 0),
+                                                  (2, 3, 5, 70, False, 0)])
+def test_small_attention_forward_and_backward(B, H, Lq, Sk, causal, off):
+    from mlx8_ws_audio_transformer_amd import native_decoder as nd
+    d = H * 64
+    q, k, v, do = _rand((B * Lq, d), 1), _rand((B * Sk, d), 2), _rand((B * Sk, d), 3), _rand((B * Lq, d), 4)
+    o, lse = nd.attention_small((q, 0), d, (k, 0), d, (v, 0), d, B, H, Lq, Sk, causal, off)
+    qd, kd, vd = (t.double().requires_grad_(True) for t in (q, k, v))
+    qh = qd.view(B, Lq, H, 64).transpose(1, 2); kh = kd.view(B, Sk, H, 64).transpose(1, 2); vh = vd.view(B, Sk, H, 64).transpose(1, 2)
+    s = (qh * 0.125) @ kh.transpose(2, 3)
+    if causal:
+        i, j = torch.arange(Lq, device="cuda")[:, None], torch.arange(Sk, device="cuda")[None, :]
+        s = s.masked_fill(j > i + off, float("-inf"))
+    ref = (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(B * Lq, d)
+    assert (o.double() - ref).abs().max().item() < 2e-5
+    ref.backward(do.double())
+    dq, dk, dv = torch.full_like(q, 7.0), torch.full_like(k, 7.0), torch.full_like(v, 7.0)      # every element must be overwritten
+    nd.attention_small_backward((q, 0), d, (k, 0), d, (v, 0), d, o, do, lse, (dq, 0), (dk, 0), (dv, 0), B, H, Lq, Sk, causal, off)
+    for got, want in ((dq, qd.grad), (dk, kd.grad), (dv, vd.grad)):
+        assert (got.double() - want).abs().max().item() < 5e-5 * max(1.0, want.abs().max().item())
+
+
+def test_small_attention_reads_fused_buffers_in_place():
+    """q | k | v as column blocks of one [M, 3 d] matrix (the fused projection's output), gradients written the same way."""
+    from mlx8_ws_audio_transformer_amd import native_decoder as nd
+    B, H, L = 2, 2, 10
+    d = H * 64
+    qkv, do = _rand((B * L, 3 * d), 1), _rand((B * L, d), 2)
+    o, lse = nd.attention_small((qkv, 0), 3 * d, (qkv, d), 3 * d, (qkv, 2 * d), 3 * d, B, H, L, L, True, 0)
+    o2, _ = nd.attention_small((qkv[:, :d].contiguous(), 0), d, (qkv[:, d:2 * d].contiguous(), 0), d, (qkv[:, 2 * d:].contiguous(), 0), d, B, H, L, L, True, 0)
+    assert torch.equal(o, o2)
+    dqkv = torch.empty_like(qkv)
+    nd.attention_small_backward((qkv, 0), 3 * d, (qkv, d), 3 * d, (qkv, 2 * d), 3 * d, o, do, lse, (dqkv, 0), (dqkv, d), (dqkv, 2 * d), B, H, L, L, True, 0)
+    assert torch.isfinite(dqkv).all() and float(dqkv.abs().max()) > 0
+
+
+def test_cross_entropy_gelu_layernorm_and_embedding_ops():
+    from mlx8_ws_audio_transformer_amd import native_decoder as nd
+    M, vocab, ld = 37, 1000, 1024
+    logits = F.pad(_rand((M, vocab), 1, 3.0), (0, ld - vocab), value=50.0).contiguous()      # padding columns hold junk: they must be ignored
+    labels = torch.randint(0, vocab, (M,), generator=torch.Generator().manual_seed(2)).cuda()
+    labels[::5] = -100
+    loss, dlogits = nd.cross_entropy(logits, labels, vocab)
+    z = logits[:, :vocab].double().requires_grad_(True)
+    ref = F.cross_entropy(z, labels, ignore_index=-100)
+    ref.backward()
+    assert abs(float(loss) - float(ref)) < 1e-5
+    assert (dlogits[:, :vocab].double() - z.grad).abs().max().item() < 1e-7 and float(dlogits[:, vocab:].abs().max()) == 0.0
+    x, dy = _rand((50, 256), 3, 2.0), _rand((50, 256), 4)
+    xd = x.double().requires_grad_(True)
+    F.gelu(xd).backward(dy.double())
+    assert (nd.gelu(x).double() - F.gelu(x.double())).abs().max().item() < 1e-6
+    assert (nd.gelu_backward(x, dy).double() - xd.grad).abs().max().item() < 2e-6
+    g, b, dres = _rand((256,), 5) + 1.0, _rand((256,), 6), _rand((50, 256), 7)
+    xd = x.double().requires_grad_(True)
+    F.layer_norm(xd, (256,), g.double(), b.double(), 1e-5).backward(dy.double())
+    assert (nd.layernorm_backward(dy, x, g).double() - xd.grad).abs().max().item() < 1e-5
+    assert (nd.layernorm_backward(dy, x, g, dres=dres).double() - (xd.grad + dres.double())).abs().max().item() < 1e-5
+
+
+def _pair(native):
+    """WhisperLoRAModel (mini encoder, 2 decoder layers, vocab 512) with the deterministic weights of tests/golden/decoder.npz."""
+    from mlx8_ws_audio_transformer_amd.finetune import WhisperLoRAModel
+    cfg = wts.config("mini", True)
+    model = WhisperLoRAModel(cfg, wts.LoraSpec(r=8, alpha=16.0), decoder_layers=2, vocab=512, max_target_positions=64, native_decoder=native)
+    model.config.decoder_start_token_id, model.config.pad_token_id, model.config.eos_token_id = 1, 0, 2
+    We = wts.init_encoder_weights(cfg, seed=0, profile="test")
+    Wd = wts.init_decoder_weights(cfg.d_model, 2, cfg.ffn, 512, 64, seed=0)
+    model.encoder.load_state_dict({k: torch.from_numpy(v) for k, v in We.items()}, strict=False)
+    model.decoder.load_state_dict({k: torch.from_numpy(v) for k, v in Wd.items()}, strict=True)
+    mel = oracle_mel.whisper_logmel(piano_clips_f32(2), n_samples=2 * cfg.max_source_positions * 160)
+    return model, torch.from_numpy(mel).cuda()
+
+
+def test_native_decoder_loss_logits_and_greedy_tokens_match_reference():
+    """fineTune.py's forward (a9) and greedy decoding against WhisperForConditionalGeneration on the same weights, decoder on libawt."""
+    G = golden("decoder.npz")
+    model, mel = _pair(True)
+    model.eval()
+    with torch.no_grad():
+        out = model(input_features=mel, labels=torch.from_numpy(G["labels"]).cuda())
+    np.testing.assert_allclose(out.logits.float().cpu().numpy(), G["logits"], rtol=0, atol=2e-3)
+    assert abs(float(out.loss) - float(G["loss"])) < 1e-3
+    ids = model.generate(mel, max_length=G["greedy_ids"].shape[1]).cpu().numpy()
+    np.testing.assert_array_equal(ids, G["greedy_ids"])
+
+
+def test_native_decoder_gradients_match_the_torch_decoder():
+    """Adapter gradients of the full step (native encoder backward fed by d(loss)/d(hidden)): native decoder vs stock-PyTorch decoder."""
+    G = golden("decoder.npz")
+    labels = torch.from_numpy(G["labels"]).cuda()
+    res = {}
+    for native in (False, True):
+        model, mel = _pair(native)
+        with torch.no_grad():
+            for p in model.lora_parameters():
+                if p.shape[1] == 8:
+                    p.copy_(torch.from_numpy(0.05 * wts.unit_variates("ndec", p.numel(), 1).reshape(p.shape).astype(np.float32)))
+        out = model(input_features=mel, labels=labels)
+        out.loss.backward()
+        res[native] = (float(out.loss), torch.cat([p.grad.flatten() for p in model.lora_parameters()]).cpu(), out.logits.float().cpu())
+    assert abs(res[True][0] - res[False][0]) < 2e-4 * abs(res[False][0])
+    assert float((res[True][2] - res[False][2]).abs().max()) < 2e-3
+    ref = res[False][1]
+    assert float(ref.abs().max()) > 0
+    assert float((res[True][1] - ref).abs().max()) < 2e-3 * float(ref.abs().max())
