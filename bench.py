@@ -62,11 +62,13 @@ def parse():
     ap.add_argument("--chunk", type=int, default=0, help="clips per kernel wave inside the library (0 = default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fast-mode", action="store_true")
+    ap.add_argument("--no-power", action="store_true", help="do not start the rocm-smi sampler process (profiler runs: every child would be traced)")
     ap.add_argument("--cpu-clips", type=int, default=8)
     ap.add_argument("--workload", default="encode", choices=["encode", "sweep", "finetune", "noop"])
     ap.add_argument("--clips", type=int, default=10000, help="sweep workload: clips in the whole set (sharded over the ranks)")
     ap.add_argument("--lora-r", type=int, default=8)
-    ap.add_argument("--decoder-dtype", default="fp32", choices=["fp32", "bf16"], help="finetune workload: dtype of the stock-PyTorch decoder")
+    ap.add_argument("--decoder-dtype", default="fp32", choices=["fp32", "bf16"], help="finetune workload with --torch-decoder: dtype of the stock-PyTorch decoder")
+    ap.add_argument("--torch-decoder", action="store_true", help="finetune workload: stock-PyTorch decoder + CE instead of the native ones (A/B)")
     ap.add_argument("--backward-precision", default=None, choices=["bf16"],
                     help="finetune workload: gradient contractions in single bf16 products (opt-in; default = the forward's precision)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -249,8 +251,8 @@ def finetune_main(a):
     B = a.batch
     pcm = torch.from_numpy(synth.synth_clips_i16(B, seed=1234, first=rank * B)).to(dev)
     model = WhisperLoRAModel(cfg, wts.LoraSpec(r=a.lora_r, alpha=16.0), precision=a.precision, device=str(dev),
-                             decoder_autocast=torch.bfloat16 if a.decoder_dtype == "bf16" else None,
-                             backward_precision=a.backward_precision)
+                             decoder_autocast=torch.bfloat16 if (a.decoder_dtype == "bf16" and a.torch_decoder) else None,
+                             backward_precision=a.backward_precision, native_decoder=not a.torch_decoder)
     g = torch.Generator().manual_seed(rank)
     labels = torch.randint(0, 51864, (B, 12), generator=g); labels[:, 0] = 50258
     args = Seq2SeqTrainingArguments(per_device_train_batch_size=B, learning_rate=1e-5, max_steps=10 ** 6, predict_with_generate=False)
@@ -270,7 +272,8 @@ def finetune_main(a):
             "metric": "4s@16kHz clips/sec through mel+Whisper-%s LoRA fine-tune step" % a.model, "value": round(B * world * a.steps / dt, 2),
             "unit": "clips/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "LoRA r=%d (q_proj, v_proj) fine-tune step: log-mel + encoder fwd/bwd (HIP) + decoder/CE (torch) + gradient exchange + AdamW" % a.lora_r,
+            "config": {"workload": "LoRA r=%d (q_proj, v_proj) fine-tune step: log-mel + encoder fwd/bwd (HIP) + decoder/CE (%s) + gradient exchange + AdamW" % (
+                           a.lora_r, "torch" if a.torch_decoder else "HIP"),
                        "clips_per_gpu_per_step": B, "global_batch": B * world, "precision": a.precision, "label_tokens": 12, "decoder_dtype": a.decoder_dtype,
                        "backward_precision": a.backward_precision or a.precision,
                        "adapter_grad_elems": tr.bucket.numel, "gradient_exchange": tr.exchange,
@@ -433,7 +436,7 @@ def outlier_profile(a, torch, dev):
 
 
 def encode_main(a):
-    sampler = PowerSampler() if (int(os.environ.get("RANK", "0")) == 0 and a.gpus == 1) else None   # before the GPU is initialised
+    sampler = PowerSampler() if (int(os.environ.get("RANK", "0")) == 0 and a.gpus == 1 and not a.no_power) else None   # before the GPU is initialised
     R = Ranks(a)
     torch, dev, rank, world = R.torch, R.dev, R.rank, R.world
     from mlx8_ws_audio_transformer_amd import _lib, synth, weights as wts

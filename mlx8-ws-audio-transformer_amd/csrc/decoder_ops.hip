@@ -198,8 +198,7 @@ __global__ void ce_reduce_kernel(const float* row_loss, int M, const int* count,
 // ------------------------------------------------------------------------------------------------ small attention (fp32)
 // q: row (b, i) at q + (b Lq + i) ldq + 64 h;  k, v: row (b, j) at k + (b Sk + j) ldk + 64 h;  o like q with ldo.
 // score(i, j) = 0.125 q_i . k_j (the reference scales q by head_dim^-1/2 before the product, HF:modeling_whisper.py:309), keys
-// j <= i + causal_off only when causal.  One wave per (b, h, i): lane = key inside a 64-key chunk for the scores, lane = output
-// dimension for the weighted sum (probabilities broadcast lane by lane).
+// j <= i + causal_off only when causal.
 struct SmallAttn {
   const float *q, *k, *v; float* o; float* lse;
   const float *dout; float *dq, *dk, *dv; float* delta;
@@ -217,82 +216,157 @@ __device__ __forceinline__ float wave_sum(float x) {
   return x;
 }
 
+// Forward.  A workgroup owns QB = 16 query rows of one (batch, head) so that K and V are read once per 16 queries; its four waves
+// take the 64-key chunks round robin and keep their own running (max, sum, output) per query, merged at the end.  Per chunk a
+// wave (1) has lane j compute the 16 scores of key j against the query tile in LDS (the key row lives in the lane's registers),
+// (2) exponentiates with wave-wide max / sum per query and parks the probabilities in LDS, (3) turns its lanes into output
+// dimensions and accumulates p V with the chunk's V rows read coalesced and the probabilities broadcast from LDS.
+constexpr int QB = 16;
+
 __global__ __launch_bounds__(256) void small_attn_fwd_kernel(SmallAttn a) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);           // (b, h, i)
-  if (row >= a.B * a.H * a.Lq) return;
-  const int i = row % a.Lq, bh = row / a.Lq, h = bh % a.H, b = bh / a.H;
-  const float* qp = a.q + ((int64_t)b * a.Lq + i) * a.ldq + 64 * h;
+  __shared__ __attribute__((aligned(16))) float qs[QB][64];
+  __shared__ __attribute__((aligned(16))) float ps[4][QB][64];
+  __shared__ float pm[4][QB], plsum[4][QB];
+  __shared__ float po[4][QB][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int bh = blockIdx.x, h = bh % a.H, b = bh / a.H;
+  const int i0 = blockIdx.y * QB, nq = min(QB, a.Lq - i0);
   const float* kp = a.k + (int64_t)b * a.Sk * a.ldk + 64 * h;
   const float* vp = a.v + (int64_t)b * a.Sk * a.ldv + 64 * h;
-  float q[64];
-#pragma unroll
-  for (int e = 0; e < 64; e += 4) { const float4 t = *reinterpret_cast<const float4*>(qp + e); q[e] = t.x * 0.125f; q[e + 1] = t.y * 0.125f; q[e + 2] = t.z * 0.125f; q[e + 3] = t.w * 0.125f; }
-  const int last = a.causal ? min(a.Sk - 1, i + a.causal_off) : a.Sk - 1;
-  float m_run = -3.0e38f, l_run = 0.f, acc = 0.f;               // acc: output dimension `lane`
-  for (int j0 = 0; j0 <= last; j0 += 64) {
-    const int j = j0 + lane;
-    float s = -3.0e38f;
-    if (j <= last) {
-      const float* kr = kp + (int64_t)j * a.ldk;
-      float d = 0.f;
-#pragma unroll
-      for (int e = 0; e < 64; e += 4) { const float4 t = *reinterpret_cast<const float4*>(kr + e); d += q[e] * t.x + q[e + 1] * t.y + q[e + 2] * t.z + q[e + 3] * t.w; }
-      s = d;
-    }
-    const float m_new = fmaxf(m_run, wave_max(s));
-    const float alpha = __expf(m_run - m_new);
-    const float p = j <= last ? __expf(s - m_new) : 0.f;
-    l_run = l_run * alpha + wave_sum(p);
-    acc *= alpha;
-    const int nk = min(64, last - j0 + 1);
-    for (int t = 0; t < nk; ++t) acc += __shfl(p, t) * vp[(int64_t)(j0 + t) * a.ldv + lane];
-    m_run = m_new;
+  for (int t = threadIdx.x; t < QB * 64; t += 256) {
+    const int i = t >> 6, e = t & 63;
+    qs[i][e] = i < nq ? a.q[((int64_t)b * a.Lq + i0 + i) * a.ldq + 64 * h + e] * 0.125f : 0.f;
   }
-  a.o[((int64_t)b * a.Lq + i) * a.ldo + 64 * h + lane] = acc / l_run;
-  if (a.lse && lane == 0) a.lse[row] = m_run + __logf(l_run);
+  __syncthreads();
+  float m[QB], l[QB], o[QB];
+#pragma unroll
+  for (int i = 0; i < QB; ++i) { m[i] = -3.0e38f; l[i] = 0.f; o[i] = 0.f; }
+  const int kmax = a.causal ? min(a.Sk - 1, i0 + nq - 1 + a.causal_off) : a.Sk - 1;      // last key any row of the tile sees
+  for (int c = wave; c * 64 <= kmax; c += 4) {
+    const int j = c * 64 + lane;
+    const float* kr = kp + (int64_t)min(j, a.Sk - 1) * a.ldk;
+    float k[64];
+#pragma unroll
+    for (int e = 0; e < 64; e += 4) { const float4 t = *reinterpret_cast<const float4*>(kr + e); k[e] = t.x; k[e + 1] = t.y; k[e + 2] = t.z; k[e + 3] = t.w; }
+#pragma unroll
+    for (int i = 0; i < QB; ++i) {
+      float s = 0.f;
+#pragma unroll
+      for (int e = 0; e < 64; e += 4) { const float4 t = *reinterpret_cast<const float4*>(&qs[i][e]); s += t.x * k[e] + t.y * k[e + 1] + t.z * k[e + 2] + t.w * k[e + 3]; }
+      const bool ok = j <= kmax && i < nq && (!a.causal || j <= i0 + i + a.causal_off);
+      s = ok ? s : -3.0e38f;
+      const float m_new = fmaxf(m[i], wave_max(s));
+      const float alpha = __expf(m[i] - m_new);
+      const float p = ok ? __expf(s - m_new) : 0.f;
+      l[i] = l[i] * alpha + wave_sum(p);
+      m[i] = m_new;
+      o[i] *= alpha;
+      ps[wave][i][lane] = p;
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int j4 = 0; j4 < 64; j4 += 4) {                      // lane = output dimension from here on
+      const int jb = c * 64 + j4;
+      const float v0 = vp[(int64_t)min(jb, a.Sk - 1) * a.ldv + lane], v1 = vp[(int64_t)min(jb + 1, a.Sk - 1) * a.ldv + lane];
+      const float v2 = vp[(int64_t)min(jb + 2, a.Sk - 1) * a.ldv + lane], v3 = vp[(int64_t)min(jb + 3, a.Sk - 1) * a.ldv + lane];
+#pragma unroll
+      for (int i = 0; i < QB; ++i) {
+        const float4 p4 = *reinterpret_cast<const float4*>(&ps[wave][i][j4]);      // zero for masked keys
+        o[i] += p4.x * v0 + p4.y * v1 + p4.z * v2 + p4.w * v3;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+#pragma unroll
+  for (int i = 0; i < QB; ++i) { po[wave][i][lane] = o[i]; if (lane == 0) { pm[wave][i] = m[i]; plsum[wave][i] = l[i]; } }
+  __syncthreads();
+  for (int t = threadIdx.x; t < nq * 64; t += 256) {
+    const int i = t >> 6, e = t & 63;
+    const float M = fmaxf(fmaxf(pm[0][i], pm[1][i]), fmaxf(pm[2][i], pm[3][i]));
+    float L = 0.f, O = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { const float f = __expf(pm[w][i] - M); L += plsum[w][i] * f; O += po[w][i][e] * f; }
+    a.o[((int64_t)b * a.Lq + i0 + i) * a.ldo + 64 * h + e] = O / L;
+    if (a.lse && e == 0) a.lse[(int64_t)bh * a.Lq + i0 + i] = M + __logf(L);
+  }
 }
 
-// dq (and delta = rowsum(dO * O)): the forward's structure with dp_j = dO_i . v_j in place of the scores' role
+// dq (and delta = rowsum(dO * O)): the same tiling; lane j forms ds_ij = p_ij (dO_i . v_j - delta_i) for the 16 rows, then the lanes
+// become dimensions and accumulate ds K with the chunk's K rows read coalesced.
 __global__ __launch_bounds__(256) void small_attn_dq_kernel(SmallAttn a) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= a.B * a.H * a.Lq) return;
-  const int i = row % a.Lq, bh = row / a.Lq, h = bh % a.H, b = bh / a.H;
-  const int64_t qoff = ((int64_t)b * a.Lq + i) * a.ldq + 64 * h, ooff = ((int64_t)b * a.Lq + i) * a.ldo + 64 * h;
+  __shared__ __attribute__((aligned(16))) float qs[QB][64];
+  __shared__ __attribute__((aligned(16))) float gs[QB][64];
+  __shared__ __attribute__((aligned(16))) float dss[4][QB][64];
+  __shared__ float lses[QB], deltas[QB];
+  __shared__ float pq[4][QB][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int bh = blockIdx.x, h = bh % a.H, b = bh / a.H;
+  const int i0 = blockIdx.y * QB, nq = min(QB, a.Lq - i0);
   const float* kp = a.k + (int64_t)b * a.Sk * a.ldk + 64 * h;
   const float* vp = a.v + (int64_t)b * a.Sk * a.ldv + 64 * h;
-  float q[64], g[64];
-#pragma unroll
-  for (int e = 0; e < 64; e += 4) {
-    const float4 t = *reinterpret_cast<const float4*>(a.q + qoff + e), u = *reinterpret_cast<const float4*>(a.dout + ooff + e);
-    q[e] = t.x * 0.125f; q[e + 1] = t.y * 0.125f; q[e + 2] = t.z * 0.125f; q[e + 3] = t.w * 0.125f;
-    g[e] = u.x; g[e + 1] = u.y; g[e + 2] = u.z; g[e + 3] = u.w;
+  for (int t = threadIdx.x; t < QB * 64; t += 256) {
+    const int i = t >> 6, e = t & 63;
+    const int64_t ro = ((int64_t)b * a.Lq + i0 + i) * a.ldq + 64 * h + e, oo = ((int64_t)b * a.Lq + i0 + i) * a.ldo + 64 * h + e;
+    qs[i][e] = i < nq ? a.q[ro] * 0.125f : 0.f;
+    gs[i][e] = i < nq ? a.dout[oo] : 0.f;
   }
-  const float delta = wave_sum(a.dout[ooff + lane] * a.o[ooff + lane]);
-  if (lane == 0) a.delta[row] = delta;
-  const float lse = a.lse[row];
-  const int last = a.causal ? min(a.Sk - 1, i + a.causal_off) : a.Sk - 1;
-  float acc = 0.f;                                                // dq dimension `lane` (of the SCALED q)
-  for (int j0 = 0; j0 <= last; j0 += 64) {
-    const int j = j0 + lane;
-    float ds = 0.f;
-    if (j <= last) {
-      const float* kr = kp + (int64_t)j * a.ldk;
-      const float* vr = vp + (int64_t)j * a.ldv;
+  for (int i = wave; i < QB; i += 4) {        // delta_i = dO_i . O_i, one wave per row
+    float dlt = 0.f;
+    if (i < nq) { const int64_t oo = ((int64_t)b * a.Lq + i0 + i) * a.ldo + 64 * h + lane; dlt = wave_sum(a.dout[oo] * a.o[oo]); }
+    if (lane == 0) {
+      deltas[i] = dlt;
+      lses[i] = i < nq ? a.lse[(int64_t)bh * a.Lq + i0 + i] : 0.f;
+      if (i < nq) a.delta[(int64_t)bh * a.Lq + i0 + i] = dlt;
+    }
+  }
+  __syncthreads();
+  float dq[QB];
+#pragma unroll
+  for (int i = 0; i < QB; ++i) dq[i] = 0.f;
+  const int kmax = a.causal ? min(a.Sk - 1, i0 + nq - 1 + a.causal_off) : a.Sk - 1;
+  for (int c = wave; c * 64 <= kmax; c += 4) {
+    const int j = c * 64 + lane;
+    const float* kr = kp + (int64_t)min(j, a.Sk - 1) * a.ldk;
+    const float* vr = vp + (int64_t)min(j, a.Sk - 1) * a.ldv;
+    float k[64], v[64];
+#pragma unroll
+    for (int e = 0; e < 64; e += 4) {
+      const float4 t = *reinterpret_cast<const float4*>(kr + e), u = *reinterpret_cast<const float4*>(vr + e);
+      k[e] = t.x; k[e + 1] = t.y; k[e + 2] = t.z; k[e + 3] = t.w; v[e] = u.x; v[e + 1] = u.y; v[e + 2] = u.z; v[e + 3] = u.w;
+    }
+#pragma unroll
+    for (int i = 0; i < QB; ++i) {
       float s = 0.f, dp = 0.f;
 #pragma unroll
       for (int e = 0; e < 64; e += 4) {
-        const float4 t = *reinterpret_cast<const float4*>(kr + e), u = *reinterpret_cast<const float4*>(vr + e);
-        s += q[e] * t.x + q[e + 1] * t.y + q[e + 2] * t.z + q[e + 3] * t.w;
-        dp += g[e] * u.x + g[e + 1] * u.y + g[e + 2] * u.z + g[e + 3] * u.w;
+        const float4 t = *reinterpret_cast<const float4*>(&qs[i][e]), u = *reinterpret_cast<const float4*>(&gs[i][e]);
+        s += t.x * k[e] + t.y * k[e + 1] + t.z * k[e + 2] + t.w * k[e + 3];
+        dp += u.x * v[e] + u.y * v[e + 1] + u.z * v[e + 2] + u.w * v[e + 3];
       }
-      ds = __expf(s - lse) * (dp - delta);
+      const bool ok = j <= kmax && i < nq && (!a.causal || j <= i0 + i + a.causal_off);
+      dss[wave][i][lane] = ok ? __expf(s - lses[i]) * (dp - deltas[i]) : 0.f;
     }
-    const int nk = min(64, last - j0 + 1);
-    for (int t = 0; t < nk; ++t) acc += __shfl(ds, t) * kp[(int64_t)(j0 + t) * a.ldk + lane];
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int j4 = 0; j4 < 64; j4 += 4) {
+      const int jb = c * 64 + j4;
+      const float k0 = kp[(int64_t)min(jb, a.Sk - 1) * a.ldk + lane], k1 = kp[(int64_t)min(jb + 1, a.Sk - 1) * a.ldk + lane];
+      const float k2 = kp[(int64_t)min(jb + 2, a.Sk - 1) * a.ldk + lane], k3 = kp[(int64_t)min(jb + 3, a.Sk - 1) * a.ldk + lane];
+#pragma unroll
+      for (int i = 0; i < QB; ++i) {
+        const float4 d4 = *reinterpret_cast<const float4*>(&dss[wave][i][j4]);
+        dq[i] += d4.x * k0 + d4.y * k1 + d4.z * k2 + d4.w * k3;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
   }
-  a.dq[qoff + lane] = acc * 0.125f;
+#pragma unroll
+  for (int i = 0; i < QB; ++i) pq[wave][i][lane] = dq[i];
+  __syncthreads();
+  for (int t = threadIdx.x; t < nq * 64; t += 256) {
+    const int i = t >> 6, e = t & 63;
+    a.dq[((int64_t)b * a.Lq + i0 + i) * a.ldq + 64 * h + e] = ((pq[0][i][e] + pq[1][i][e]) + (pq[2][i][e] + pq[3][i][e])) * 0.125f;
+  }
 }
 
 // dk, dv: one lane per key, all query rows of the (batch, head) in a loop; the 64-dimensional accumulators live in registers
@@ -398,8 +472,7 @@ extern "C" int awt_op_attention_small(awt_ctx* c, const float* q, int ldq, const
   AWT_REQUIRE(c && q && k && v && o, AWT_ERR_INVALID, "op_attention_small: null argument");
   SmallAttn a{q, k, v, o, lse, nullptr, nullptr, nullptr, nullptr, nullptr, B, H, Lq, Sk, ldq, ldk, ldv, ldo, causal, causal_off};
   int rc = check_small(a, "op_attention_small"); if (rc) return rc;
-  const int rows = B * H * Lq;
-  hipLaunchKernelGGL(small_attn_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(small_attn_fwd_kernel, dim3(B * H, (Lq + QB - 1) / QB), dim3(256), 0, (hipStream_t)stream, a);
   AWT_HIP_CHECK(hipGetLastError());
   return AWT_OK;
 }
@@ -410,8 +483,7 @@ extern "C" int awt_op_attention_small_backward(awt_ctx* c, const float* q, int l
   SmallAttn a{q, k, v, const_cast<float*>(o), const_cast<float*>(lse), dout, dq, dk, dv, delta, B, H, Lq, Sk, ldq, ldk, ldv, ldo, causal, causal_off};
   int rc = check_small(a, "op_attention_small_backward"); if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
-  const int rows = B * H * Lq;
-  hipLaunchKernelGGL(small_attn_dq_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(small_attn_dq_kernel, dim3(B * H, (Lq + QB - 1) / QB), dim3(256), 0, s, a);
   hipLaunchKernelGGL(small_attn_dkv_kernel, dim3(B * H * ((Sk + 63) / 64)), dim3(64), 0, s, a);
   AWT_HIP_CHECK(hipGetLastError());
   return AWT_OK;

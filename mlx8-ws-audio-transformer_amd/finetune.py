@@ -155,10 +155,13 @@ class WhisperLoRAModel(nn.Module):
 
     def __init__(self, cfg: EncoderConfig, lora: LoraSpec, precision: str = "bf16x3", device: str = "cuda", decoder_layers: Optional[int] = None,
                  seed: int = 0, vocab: int = WHISPER_VOCAB, decoder_autocast: Optional[torch.dtype] = None, native_cross_kv: bool = True,
-                 max_target_positions: int = 448, backward_precision: Optional[str] = None, native_decoder: bool = False):
+                 max_target_positions: int = 448, backward_precision: Optional[str] = None, native_decoder: bool = True):
         super().__init__()
-        # native_decoder=True: decoder, tied projection and cross-entropy run on libawt as well (native_decoder.NativeWhisperDecoder,
-        # scope row f1); False keeps the stock-PyTorch decoder (pinned to HF by tests/golden/decoder.npz) around the native encoder
+        # native_decoder=True (default): decoder, tied projection and cross-entropy run on libawt as well (native_decoder.NativeWhisperDecoder,
+        # scope row f1); False keeps the stock-PyTorch decoder (the restatement pinned to HF by tests/golden/decoder.npz) around the
+        # native encoder -- kept as the A/B reference of the native one (tests/test_gpu_native_decoder.py)
+        if decoder_autocast is not None:
+            native_decoder = False            # autocast is a property of the torch decoder
         self.native_decoder = native_decoder
         # the decoder is stock PyTorch (scope row "next"): fp32 like the reference (fp16=False, fineTune.py:170) unless
         # decoder_autocast=torch.bfloat16 asks torch to run its matmuls in bf16

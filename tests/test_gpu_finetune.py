@@ -72,7 +72,7 @@ def test_native_cross_kv_projection_matches_torch_decoder():
     b = _batch(cfg, 3)
     out = {}
     for native in (True, False):
-        model = WhisperLoRAModel(cfg, wts.LoraSpec(r=8, alpha=16.0), decoder_layers=2, native_cross_kv=native)
+        model = WhisperLoRAModel(cfg, wts.LoraSpec(r=8, alpha=16.0), decoder_layers=2, native_cross_kv=native, native_decoder=False)
         for p in model.lora_parameters():
             if p.shape[1] == 8:
                 with torch.no_grad():

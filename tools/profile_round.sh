@@ -5,13 +5,13 @@ cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
 tag=${1:-r02}
 prec=${2:-bf16x3}
 out=gpurun_out/prof_$tag; rm -rf $out; mkdir -p $out
-args="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fast-mode --precision $prec"
+args="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fast-mode --no-power --precision $prec"
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $args > $out/trace.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc_$c -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-fast-mode --precision $prec > $out/pmc_$c.log 2>&1
+  timeout -k 10 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc_$c -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-fast-mode --no-power --precision $prec > $out/pmc_$c.log 2>&1
 done
 # MFMA utilisation and effective clock (own pass; SQ + GRBM slots)
-timeout -k 10 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_MFMA -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-fast-mode --precision $prec > $out/pmc_MFMA.log 2>&1
+timeout -k 10 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_MFMA -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-fast-mode --no-power --precision $prec > $out/pmc_MFMA.log 2>&1
 python3 - $out $tag $prec <<'PY2'
 import csv, glob, json, sys, collections
 out, tag = sys.argv[1], sys.argv[2]
