@@ -10,7 +10,8 @@
  *    awt_last_error() returns a thread-local message owned by the library;
  *  - all data pointers are CALLER-OWNED DEVICE pointers (e.g. torch tensors' data_ptr()); the library never
  *    frees caller memory and never allocates inside a compute call (tables and converted weights are
- *    allocated in *_create / *_set_weight / first-use of a table size);
+ *    allocated in *_create / *_set_weight / awt_*_prepare; only a front-end configuration that was never prepared is
+ *    built at its first use);
  *  - all work is enqueued on the caller's hipStream_t (passed as void*; NULL = default stream);
  *    no hidden synchronisation except where a function says so (awt_prof_collect);
  *  - a handle is not thread-safe; distinct handles are independent; one awt_ctx per (process, device).
@@ -85,6 +86,12 @@ int awt_logmel_generic(awt_ctx* c, const float* pcm, int64_t pcm_stride, int B, 
  *   (c, i) is at pcm[c * channel_stride + i * sample_stride] -- planar [C][n] is (n, 1), interleaved WAV data is (1, C).
  * out: float32 [n_out].  The resampled clip has awt_resampled_length() = ceil(n_in * sr_out / sr_in) samples; output
  *   samples beyond it are zero.  sr_in == sr_out skips the filter, as the reference does. */
+/* Device tables (DFT basis + mel bank of a front-end configuration; polyphase taps of a rate pair) are built once per context.
+ * awt_ctx_create builds the two Whisper front-ends' tables; call these for any other configuration BEFORE the first compute call that
+ * uses it, so that compute calls neither allocate nor synchronise (an unprepared configuration is built at first use, with a
+ * hipMalloc and a blocking copy inside that one call).  slaney != 0: Slaney scale + area normalisation (Whisper); 0: HTK, no norm. */
+int awt_logmel_prepare(awt_ctx* c, int n_fft, int n_mels, float f_min, float f_max, int sample_rate, int slaney);
+int awt_resample_prepare(awt_ctx* c, int sr_in, int sr_out);
 int64_t awt_resampled_length(int n_in, int sr_in, int sr_out);
 int awt_prepare_waveform(awt_ctx* c, const void* pcm, int pcm_is_i16, int channels, int64_t channel_stride,
                          int64_t sample_stride, int n_in, int sr_in, int sr_out, float* out, int n_out, void* stream);

@@ -47,6 +47,8 @@ _SIGNATURES = {
     "awt_logmel_whisper": (_i, [_vp, _vp, _i, _i64, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "awt_logmel_whisper_mels": (_i, [_vp, _vp, _i, _i64, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "awt_logmel_generic": (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _f, _f, _f, _vp, _vp]),
+    "awt_logmel_prepare": (_i, [_vp, _i, _i, _f, _f, _i, _i]),
+    "awt_resample_prepare": (_i, [_vp, _i, _i]),
     "awt_resampled_length": (_i64, [_i, _i, _i]),
     "awt_prepare_waveform": (_i, [_vp, _vp, _i, _i, _i64, _i64, _i, _i, _i, _vp, _i, _vp]),
     "awt_encoder_create": (_i, [_vp, C.POINTER(EncoderCfg), C.POINTER(_vp)]),

@@ -45,6 +45,11 @@ extern "C" int awt_tuning_set(const char* key, int value) {
     awt_gemm_force_tile(value);
     return AWT_OK;
   }
+  if (!strcmp(key, "gemm_gm")) {
+    AWT_REQUIRE(value >= 0 && value <= 64, AWT_ERR_INVALID, "tuning_set: gemm_gm must be 0 (default) .. 64");
+    awt_gemm_set_gm(value);
+    return AWT_OK;
+  }
   if (!strcmp(key, "attn_shape")) {
     AWT_REQUIRE(value >= 0 && value <= 5, AWT_ERR_INVALID, "tuning_set: attn_shape must be 0 (auto) or 1 .. 5");
     awt_attn_force_shape(value);
@@ -95,9 +100,18 @@ extern "C" int awt_ctx_create(int device, awt_ctx** out) {
     delete c;
     AWT_REQUIRE(false, AWT_ERR_HIP, "ctx_create: could not allocate the zero page");
   }
+  // the two Whisper front-ends' tables (DFT basis of 400, Slaney banks of 80 and 128 bins) are built here, so that no compute call
+  // of the hot path allocates or synchronises; other front-end configurations: awt_logmel_prepare / awt_resample_prepare
+  int rc = logmel_prepare_impl(c, 400, 80, 0.0, 8000.0, 16000, 1);
+  if (!rc) rc = logmel_prepare_impl(c, 400, 128, 0.0, 8000.0, 16000, 1);
+  if (rc) { awt_ctx_destroy(c); return rc; }
   *out = c;
   return AWT_OK;
 }
+extern "C" int awt_logmel_prepare(awt_ctx* c, int n_fft, int n_mels, float f_min, float f_max, int sample_rate, int slaney) {
+  return logmel_prepare_impl(c, n_fft, n_mels, (double)f_min, (double)f_max, sample_rate, slaney);
+}
+extern "C" int awt_resample_prepare(awt_ctx* c, int sr_in, int sr_out) { return resample_prepare_impl(c, sr_in, sr_out); }
 extern "C" void awt_ctx_destroy(awt_ctx* c) {
   if (!c) return;
   awt_free_tables(c);

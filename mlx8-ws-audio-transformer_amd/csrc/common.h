@@ -291,8 +291,11 @@ int logmel_generic_impl(awt_ctx* c, const float* pcm, int64_t pcm_stride, int B,
 int prepare_waveform_impl(awt_ctx* c, const void* pcm, int pcm_is_i16, int channels, int64_t channel_stride, int64_t sample_stride,
                           int n_in, int sr_in, int sr_out, float* out, int n_out, hipStream_t s);
 int64_t resampled_length(int n_in, int sr_in, int sr_out);
+int logmel_prepare_impl(awt_ctx* c, int n_fft, int n_mels, double f_min, double f_max, int sample_rate, int slaney);
+int resample_prepare_impl(awt_ctx* c, int sr_in, int sr_out);
 void awt_free_tables(awt_ctx* c);
 void awt_attn_force_shape(int v);   // f16f8 attention workgroup shape: 0 auto, 1 / 2 / 3 (attention_f8.hip)
+void awt_gemm_set_gm(int v);       // row panels per tile group of the GEMM tile order (0 = default)
 void awt_gemm_force_tile(int t);  // 0 auto, 64 / 128 / 256: tuning / tests (awt_tuning_set)
 
 // ---- backward-pass launchers

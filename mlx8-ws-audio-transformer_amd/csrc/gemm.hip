@@ -27,14 +27,20 @@
 #include <type_traits>
 #include "common.h"
 
+#ifndef AWT_GEMM_GM
+#define AWT_GEMM_GM 8   // tools/gemm_gm_sweep.py: 6 - 8 row panels per group are ~1 % ahead of 4 and 16 on every encoder shape
+#endif
+
 namespace {
 
+int g_gm = AWT_GEMM_GM;   // row panels per tile group (awt_tuning_set "gemm_gm")
 constexpr int kMaxSeg = 3;
 typedef int i32x4_t __attribute__((ext_vector_type(4)));
 
 struct GemmArgs {
   int M, N, nseg, tiles_m, tiles_n;
   int group_n;           // > 0: walk tiles in groups of group_n column tiles (weight slice L2-resident); 0: groups of GM row panels
+  int gm;                // row panels per group (tuning knob "gemm_gm"; default AWT_GEMM_GM)
   GemmSeg seg[kMaxSeg];
   GemmOut out;
   const bf16_t* zeros;   // >= 128 zero bytes (padding rows of the conv stem)
@@ -291,15 +297,12 @@ __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, 2) void gemm_kernel(GemmArg
   const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
   const int q = nwg >> 3, r = nwg & 7;
   const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-#ifndef AWT_GEMM_GM
-#define AWT_GEMM_GM 4
-#endif
   // Tile order inside an XCD's run (launch_one picks it from the shape):
   //  group_n = 0 (default): groups of GM row panels, row panel fastest -- GM activation panels stay L2-resident and each
   //    weight tile is read by GM workgroups at once.
   //  group_n > 0: groups of group_n column tiles, walked row panel by row panel: the group's weight slice stays in the
   //    XCD's 4 MB L2 for the whole pass over M; the activations are streamed tiles_n / group_n times.
-  constexpr int GM = AWT_GEMM_GM;
+  const int GM = g.gm;
   int tm, tn;
   if (g.group_n > 0) {
     const int grp = tile / (g.group_n * g.tiles_m);
@@ -477,7 +480,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f8_kernel(GemmArgs g) {
   const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
   const int qn = nwg >> 3, rn = nwg & 7;
   const int tile = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + idx;
-  constexpr int GM = AWT_GEMM_GM;
+  const int GM = g.gm;
   int tm, tn;
   {
     const int grp = tile / (GM * g.tiles_n);
@@ -686,7 +689,7 @@ int launch_f8(GemmArgs a, hipStream_t s) {
   constexpr int lds = 2 * (BM * 64 * 2 + 2 * BM * 64);     // two stages of A16 | A8 | Al8 = 64 KB (>= the epilogue patches)
   a.tiles_m = (a.M + BM - 1) / BM;
   a.tiles_n = (a.N + BN - 1) / BN;
-  a.group_n = 0;
+  a.group_n = 0; a.gm = g_gm;
   if (a.nseg == 1) {
     AWT_ONCE_PER_DEVICE(AWT_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_f8_kernel<EPI, CFG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)));
     hipLaunchKernelGGL((gemm_f8_kernel<EPI, CFG, false>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
@@ -710,7 +713,7 @@ int launch_one(GemmArgs a, hipStream_t s) {
   AWT_ONCE_PER_DEVICE(AWT_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_kernel<TERMS, BK, EPI, CFG, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES)));
   a.tiles_m = (a.M + T::BM - 1) / T::BM;
   a.tiles_n = (a.N + T::BN - 1) / T::BN;
-  a.group_n = g_group_n;
+  a.group_n = g_group_n; a.gm = g_gm;
   hipLaunchKernelGGL((gemm_kernel<TERMS, BK, EPI, CFG, F16>), dim3(a.tiles_m * a.tiles_n), dim3(T::THREADS), T::LDS_BYTES, s, a);
   AWT_HIP_CHECK(hipGetLastError());
   return AWT_OK;
@@ -759,6 +762,7 @@ int launch_epi(GemmArgs a, int prec, hipStream_t s) {
 }  // namespace
 
 void awt_gemm_force_tile(int t) { g_force_tile = t; }
+void awt_gemm_set_gm(int v) { g_gm = v > 0 ? v : AWT_GEMM_GM; }
 
 int launch_gemm(awt_ctx* c, int M, int N, const GemmSeg* segs, int nseg, int prec, GemmEpilogue epi, const GemmOut& out,
                 hipStream_t s) {

@@ -332,6 +332,19 @@ int host_live_frames(int n_valid, int n_fft, int hop, int T_out) {
 
 size_t awt_logmel_workspace_bytes(int B) { return (((size_t)(B > 0 ? B : 1) * sizeof(unsigned)) + 255) & ~(size_t)255; }
 
+// Builds (once per context) the device tables a front-end configuration needs: the DFT basis of n_fft and the mel filter bank.
+// Called from awt_ctx_create for the two Whisper front-ends and from awt_logmel_prepare for any other configuration, so that the
+// compute entry points neither allocate nor synchronise (a configuration that was never prepared is still built at first use).
+int logmel_prepare_impl(awt_ctx* c, int n_fft, int n_mels, double f_min, double f_max, int sample_rate, int slaney) {
+  AWT_REQUIRE(c, AWT_ERR_INVALID, "logmel_prepare: null context");
+  AWT_REQUIRE(n_fft == 400 || n_fft == 512 || n_fft == 1024, AWT_ERR_INVALID, "logmel_prepare: n_fft must be 400, 512 or 1024");
+  AWT_REQUIRE(n_mels > 0 && n_mels <= 128 && sample_rate > 0, AWT_ERR_INVALID, "logmel_prepare: n_mels must be in 1..128");
+  BasisTable bt; MelTable mt;
+  int rc = get_basis(c, n_fft, nullptr, &bt); if (rc) return rc;
+  return get_mel(c, n_fft / 2 + 1, n_mels, f_min, f_max, sample_rate, slaney != 0, &mt);
+}
+int resample_prepare_impl(awt_ctx* c, int sr_in, int sr_out);
+
 int logmel_whisper_impl(awt_ctx* c, const void* pcm, int pcm_is_i16, int64_t pcm_stride, const int32_t* n_valid,
                         int max_valid, int B, int n_frames_out, int n_mels, float* out, void* workspace, size_t ws_bytes, hipStream_t s) {
   AWT_REQUIRE(c && pcm && out && workspace, AWT_ERR_INVALID, "logmel_whisper: null argument");
@@ -472,6 +485,14 @@ int64_t resampled_length(int n_in, int sr_in, int sr_out) {   // ceil(new * n / 
   while (b) { const int r = a % b; a = b; b = r; }
   const int64_t orig = sr_in / a, outp = sr_out / a;
   return ((int64_t)outp * n_in + orig - 1) / orig;
+}
+
+int resample_prepare_impl(awt_ctx* c, int sr_in, int sr_out) {
+  AWT_REQUIRE(c, AWT_ERR_INVALID, "resample_prepare: null context");
+  AWT_REQUIRE(sr_in >= 1000 && sr_in <= 768000 && sr_out >= 1000 && sr_out <= 768000, AWT_ERR_INVALID, "resample_prepare: sample rates must be in 1 kHz .. 768 kHz");
+  if (sr_in == sr_out) return AWT_OK;
+  ResampleTable t{};
+  return get_resample(c, sr_in, sr_out, &t);
 }
 
 int prepare_waveform_impl(awt_ctx* c, const void* pcm, int pcm_is_i16, int channels, int64_t channel_stride, int64_t sample_stride,

@@ -149,6 +149,7 @@ class NativeWhisperEncoder(nn.Module):
         self._handle = None
         self._chunk = chunk_clips
         self._synced: Dict[str, int] = {}
+        self._param_cache = None
         self._ws: Optional[torch.Tensor] = None
         # bound gradient buffer (bind_grad_buffer) and the communicator its exchange runs on (set_comm)
         self._grad_flat: Optional[torch.Tensor] = None
@@ -192,8 +193,12 @@ class NativeWhisperEncoder(nn.Module):
         self._ensure_handle()
         L = _lib.lib()
         n = 0
+        if self._param_cache is None:      # walking the module tree costs more than the version checks: do it once
+            self._param_cache = list(self.named_parameters())
+        if not force and all(self._synced.get(name) == p._version for name, p in self._param_cache):
+            return 0
         with torch.cuda.device(self.device):
-            for name, p in self.named_parameters():
+            for name, p in self._param_cache:
                 ver = p._version
                 if not force and self._synced.get(name) == ver:
                     continue
@@ -259,7 +264,20 @@ class NativeWhisperEncoder(nn.Module):
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
         res = super().load_state_dict(state_dict, strict=strict, **kw)
         self._synced.clear()
+        self._param_cache = None
         return res
+
+    def _apply(self, fn, *a, **kw):          # .to() / .cuda() / .float() replace parameter tensors
+        self._param_cache = None
+        self._synced.clear()
+        return super()._apply(fn, *a, **kw)
+
+    def close(self) -> None:
+        """Release the library handle now (also done when the module is garbage-collected)."""
+        if self._handle is not None:
+            _lib.lib().awt_encoder_destroy(self._handle)
+            self._handle = None
+            self._synced.clear()
 
     def _workspace(self, nbytes: int) -> torch.Tensor:
         if self._ws is None or self._ws.numel() < nbytes or self._ws.device != self.device:

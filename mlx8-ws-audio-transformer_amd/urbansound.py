@@ -44,6 +44,9 @@ def get_processed_parquet_path() -> str:
     return os.path.join(PROCESSED_PARQUET_PATH, get_processed_parquet_filename())
 
 
+_PREPARED: set = set()     # front-end configurations whose device tables exist (awt_logmel_prepare / awt_resample_prepare)
+
+
 def prepare_waveform(waveform: torch.Tensor, sample_rate: int = SAMPLE_RATE, duration: float = DURATION,
                      target_rate: int = SAMPLE_RATE, interleaved: bool = False, n_out: Optional[int] = None) -> torch.Tensor:
     """[C, n] or [n] at `sample_rate` -> [1, int(target_rate * duration)] fp32: channel mean, resample to `target_rate`
@@ -80,6 +83,10 @@ def prepare_waveform(waveform: torch.Tensor, sample_rate: int = SAMPLE_RATE, dur
         cstride, sstride = n_in, 1
     out = torch.empty((1, n_out), dtype=torch.float32, device=w.device)
     with torch.cuda.device(w.device):
+        key = ("rs", w.device.index, int(sample_rate), int(target_rate))
+        if key not in _PREPARED:       # polyphase taps of this rate pair: built once, outside the compute call
+            _lib.check(_lib.lib().awt_resample_prepare(_lib.ctx(w.device), int(sample_rate), int(target_rate)))
+            _PREPARED.add(key)
         _lib.check(_lib.lib().awt_prepare_waveform(_lib.ctx(w.device), _lib.ptr(w), int(w.dtype == torch.int16), channels, cstride,
                                                    sstride, n_in, int(sample_rate), int(target_rate), _lib.ptr(out), n_out,
                                                    _lib.stream_handle()))
@@ -119,6 +126,10 @@ def mel_spectrogram_log(waveform: torch.Tensor, sample_rate: int = None, n_fft: 
     B, n = w.shape
     out = torch.empty((B, n_mels, 1 + n // hop_length), dtype=torch.float32, device=w.device)
     with torch.cuda.device(w.device):
+        key = ("mel", w.device.index, n_fft, n_mels, float(f_min), float(f_max), sample_rate)
+        if key not in _PREPARED:       # device tables of this front-end configuration: built once, outside the compute call
+            _lib.check(_lib.lib().awt_logmel_prepare(_lib.ctx(w.device), n_fft, n_mels, float(f_min), float(f_max), sample_rate, 0))
+            _PREPARED.add(key)
         _lib.check(_lib.lib().awt_logmel_generic(_lib.ctx(w.device), _lib.ptr(w), w.stride(0), B, n, sample_rate, n_fft, hop_length,
                                                  n_mels, float(f_min), float(f_max), float(log_eps), _lib.ptr(out),
                                                  _lib.stream_handle()))
