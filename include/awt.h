@@ -246,6 +246,13 @@ int awt_op_gelu_backward(awt_ctx* c, const float* x, const float* dy, float* dx,
  * residual connection; dx may alias dres) */
 int awt_op_layernorm_backward(awt_ctx* c, const float* dy, const float* x, const float* gamma, const float* dres, float* dx, int M, int d,
                               float eps, void* stream);
+/* Parameter gradients of trainable consumers of the operators (the UrbanSound8K Transformer classifier trains every weight,
+ * /root/reference/.charles/spectrogram.py:1059-1130).  dgamma[c] = sum_m dy[m, c] xhat[m, c], dbeta[c] = sum_m dy[m, c];
+ * column_sums: sums[c] = sum_m a[m, c] (bias gradients).  Deterministic two-pass reductions; d <= 1280. */
+size_t awt_op_param_grad_workspace_bytes(int M, int d);
+int awt_op_layernorm_param_grad(awt_ctx* c, const float* dy, const float* x, float* dgamma, float* dbeta, int M, int d, float eps,
+                                void* workspace, size_t ws_bytes, void* stream);
+int awt_op_column_sums(awt_ctx* c, const float* a, float* sums, int M, int d, void* workspace, size_t ws_bytes, void* stream);
 /* CrossEntropyLoss(ignore_index = -100, mean) over the first `vocab` of `ld` columns: *loss and d(loss)/d(logits) [M, ld]
  * (padding columns zero).  scratch: (M + 1) * 4 bytes.                    HF:modeling_whisper.py:1079-1086 */
 int awt_op_cross_entropy(awt_ctx* c, const float* logits, const int64_t* labels, int M, int vocab, int ld, float* loss, float* dlogits,

@@ -85,6 +85,9 @@ _SIGNATURES = {
     "awt_op_gelu": (_i, [_vp, _vp, _vp, _i64, _vp]),
     "awt_op_gelu_backward": (_i, [_vp, _vp, _vp, _vp, _i64, _vp]),
     "awt_op_layernorm_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    "awt_op_param_grad_workspace_bytes": (_sz, [_i, _i]),
+    "awt_op_layernorm_param_grad": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _sz, _vp]),
+    "awt_op_column_sums": (_i, [_vp, _vp, _vp, _i, _i, _vp, _sz, _vp]),
     "awt_op_cross_entropy": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "awt_op_attention_small": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "awt_op_attention_small_backward": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

@@ -216,6 +216,70 @@ __device__ __forceinline__ float wave_sum(float x) {
   return x;
 }
 
+// ---------------------------------------------------------------------------------------------- parameter-gradient reductions
+// (trainable consumers of the operators: the UrbanSound8K Transformer classifier, /root/reference/.charles/spectrogram.py:944-1160)
+// Column sums over a slab of rows: sums[c] = sum_m a[m, c] (bias gradients) and, for LayerNorm, dgamma[c] = sum_m dy[m, c] xhat[m, c],
+// dbeta[c] = sum_m dy[m, c].  One workgroup per slab of kSlabRows rows; wave w takes rows w, w + 4, ...; a lane owns columns
+// lane + 64 j.  Partials land in [slab][2][d] and a second kernel adds the slabs in a fixed order (deterministic, no atomics).
+constexpr int kSlabRows = 256;
+constexpr int kColMaxChunks = 20;          // d <= 1280
+__global__ __launch_bounds__(256) void ln_param_grad_kernel(const float* __restrict__ dy, const float* __restrict__ x, int M, int d, float eps,
+                                                            float* __restrict__ partial) {
+  __shared__ float red[2][4][64 * 4];      // reused per chunk group of 4
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nch = (d + 63) / 64;
+  const int r0 = blockIdx.x * kSlabRows, r1 = min(M, r0 + kSlabRows);
+  float dg[kColMaxChunks], db[kColMaxChunks];
+#pragma unroll
+  for (int j = 0; j < kColMaxChunks; ++j) dg[j] = db[j] = 0.f;
+  for (int m = r0 + wave; m < r1; m += 4) {
+    const float* xr = x ? x + (int64_t)m * d : nullptr;
+    const float* gr = dy + (int64_t)m * d;
+    float mean = 0.f, rstd = 1.f;
+    float xv[kColMaxChunks];
+    if (xr) {
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < kColMaxChunks; ++j) { const int c = lane + 64 * j; xv[j] = (j < nch && c < d) ? xr[c] : 0.f; s += xv[j]; }
+      mean = wave_sum(s) / (float)d;
+      float sq = 0.f;
+#pragma unroll
+      for (int j = 0; j < kColMaxChunks; ++j) { const int c = lane + 64 * j; const float t = (j < nch && c < d) ? xv[j] - mean : 0.f; sq += t * t; }
+      rstd = rsqrtf(wave_sum(sq) / (float)d + eps);
+    }
+#pragma unroll
+    for (int j = 0; j < kColMaxChunks; ++j) {
+      const int c = lane + 64 * j;
+      if (j < nch && c < d) { const float g = gr[c]; db[j] += g; if (xr) dg[j] += g * (xv[j] - mean) * rstd; }
+    }
+  }
+  // waves -> one partial row per slab
+  for (int j0 = 0; j0 < nch; j0 += 4) {
+    __syncthreads();
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      float a = 0.f, b = 0.f;
+#pragma unroll
+      for (int j = 0; j < kColMaxChunks; ++j) if (j == j0 + jj) { a = dg[j]; b = db[j]; }
+      red[0][wave][jj * 64 + lane] = a; red[1][wave][jj * 64 + lane] = b;
+    }
+    __syncthreads();
+    const int c = j0 * 64 + threadIdx.x;
+    if (c < d) {
+      const int t = threadIdx.x;
+      partial[((int64_t)blockIdx.x * 2 + 0) * d + c] = (red[0][0][t] + red[0][1][t]) + (red[0][2][t] + red[0][3][t]);
+      partial[((int64_t)blockIdx.x * 2 + 1) * d + c] = (red[1][0][t] + red[1][1][t]) + (red[1][2][t] + red[1][3][t]);
+    }
+  }
+}
+__global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ partial, int nslab, int d, float* out0, float* out1) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= d) return;
+  float a = 0.f, b = 0.f;
+  for (int s = 0; s < nslab; ++s) { a += partial[((int64_t)s * 2 + 0) * d + c]; b += partial[((int64_t)s * 2 + 1) * d + c]; }
+  if (out0) out0[c] = a;
+  if (out1) out1[c] = b;
+}
+
 // Forward.  A workgroup owns QB = 16 query rows of one (batch, head) so that K and V are read once per 16 queries; its four waves
 // take the 64-key chunks round robin and keep their own running (max, sum, output) per query, merged at the end.  Per chunk a
 // wave (1) has lane j compute the 16 scores of key j against the query tile in LDS (the key row lives in the lane's registers),
@@ -454,6 +518,27 @@ extern "C" int awt_op_gelu_backward(awt_ctx* c, const float* x, const float* dy,
 extern "C" int awt_op_layernorm_backward(awt_ctx* c, const float* dy, const float* x, const float* gamma, const float* dres, float* dx, int M,
                                          int d, float eps, void* stream) {
   return launch_layernorm_bwd(c, dy, x, gamma, dres, M, d, eps, dx, nullptr, nullptr, (hipStream_t)stream);
+}
+extern "C" size_t awt_op_param_grad_workspace_bytes(int M, int d) { return (size_t)((M + kSlabRows - 1) / kSlabRows) * 2 * (size_t)d * 4; }
+extern "C" int awt_op_layernorm_param_grad(awt_ctx* c, const float* dy, const float* x, float* dgamma, float* dbeta, int M, int d, float eps,
+                                           void* workspace, size_t ws_bytes, void* stream) {
+  AWT_REQUIRE(c && dy && x && dgamma && dbeta && workspace && M > 0 && d > 0 && d <= 64 * kColMaxChunks, AWT_ERR_INVALID,
+              "op_layernorm_param_grad: bad argument (d <= 1280)");
+  AWT_REQUIRE(ws_bytes >= awt_op_param_grad_workspace_bytes(M, d), AWT_ERR_WORKSPACE, "op_layernorm_param_grad: workspace too small");
+  const int nslab = (M + kSlabRows - 1) / kSlabRows;
+  hipLaunchKernelGGL(ln_param_grad_kernel, dim3(nslab), dim3(256), 0, (hipStream_t)stream, dy, x, M, d, eps, (float*)workspace);
+  hipLaunchKernelGGL(slab_sum_kernel, dim3((d + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, nslab, d, dgamma, dbeta);
+  AWT_HIP_CHECK(hipGetLastError());
+  return AWT_OK;
+}
+extern "C" int awt_op_column_sums(awt_ctx* c, const float* a, float* sums, int M, int d, void* workspace, size_t ws_bytes, void* stream) {
+  AWT_REQUIRE(c && a && sums && workspace && M > 0 && d > 0 && d <= 64 * kColMaxChunks, AWT_ERR_INVALID, "op_column_sums: bad argument (d <= 1280)");
+  AWT_REQUIRE(ws_bytes >= awt_op_param_grad_workspace_bytes(M, d), AWT_ERR_WORKSPACE, "op_column_sums: workspace too small");
+  const int nslab = (M + kSlabRows - 1) / kSlabRows;
+  hipLaunchKernelGGL(ln_param_grad_kernel, dim3(nslab), dim3(256), 0, (hipStream_t)stream, a, (const float*)nullptr, M, d, 0.f, (float*)workspace);
+  hipLaunchKernelGGL(slab_sum_kernel, dim3((d + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, nslab, d, (float*)nullptr, sums);
+  AWT_HIP_CHECK(hipGetLastError());
+  return AWT_OK;
 }
 extern "C" int awt_op_cross_entropy(awt_ctx* c, const float* logits, const int64_t* labels, int M, int vocab, int ld, float* loss, float* dlogits,
                                     void* scratch /* >= (M + 1) * 4 bytes */, void* stream) {

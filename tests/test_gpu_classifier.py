@@ -39,8 +39,89 @@ def test_logits_and_features_match_reference_module(n_mels, T, batch):
     assert torch.equal(got.argmax(-1), want.argmax(-1))
 
 
-def test_training_mode_raises_instead_of_falling_back():
-    _, nat = _pair(128, 126, seed=1)
-    nat.train()
-    with pytest.raises(NotImplementedError):
-        nat(torch.zeros(1, 128, 126).cuda())
+def _train_pair(n_mels, T, seed, dropout=0.0):
+    from mlx8_ws_audio_transformer_amd.urbansound_classifier import TransformerUrbanSound8KClassifier
+    ref, _ = _pair(n_mels, T, seed)
+    ref0 = ReferenceTransformerClassifier(n_mels=n_mels, dropout=dropout)
+    ref0.pos_embed = torch.nn.Parameter(ref.pos_embed.detach().clone()); ref0.n_frames = T
+    ref0.load_state_dict(ref.state_dict())
+    nat = TransformerUrbanSound8KClassifier(n_mels=n_mels, dropout=dropout)
+    nat.pos_embed = torch.nn.Parameter(ref.pos_embed.detach().clone()); nat.n_frames = T
+    nat.load_state_dict(ref.state_dict())
+    return ref0.train(), nat.cuda().train()
+
+
+@pytest.mark.parametrize("n_mels,T,batch", [(128, 126, 4), (64, 501, 2)])
+def test_training_step_gradients_match_autograd_of_the_reference_module(n_mels, T, batch):
+    """One forward + backward in train() mode with dropout 0: loss and the gradient of EVERY parameter against torch autograd over
+    the reference module's restatement (fp32 CPU).  Tolerance: 2e-4 of each gradient's largest magnitude (bf16x3 GEMMs, the
+    weight-gradient contraction runs over B (T + 1) rows)."""
+    from mlx8_ws_audio_transformer_amd.urbansound_classifier import native_cross_entropy
+    ref, nat = _train_pair(n_mels, T, seed=7 + T)
+    x = torch.from_numpy(wts.unit_variates("cls.xt", batch * n_mels * T, 5).reshape(batch, n_mels, T).astype(np.float32)) * 2.0 - 4.0
+    y = torch.tensor([(3 * i + 1) % 10 for i in range(batch)])
+    want_loss = torch.nn.CrossEntropyLoss()(ref(x), y)
+    want_loss.backward()
+    got_loss = native_cross_entropy(nat(x.cuda()), y.cuda())
+    got_loss.backward()
+    assert abs(float(got_loss) - float(want_loss)) < 1e-4
+    want = dict(ref.named_parameters())
+    checked = 0
+    for name, p in nat.named_parameters():
+        assert p.grad is not None, name
+        g, w = p.grad.cpu(), want[name].grad
+        scale = float(w.abs().max())
+        assert scale > 0, name
+        err = float((g - w).abs().max())
+        assert err <= 2e-4 * scale + 1e-7, (name, err, scale)
+        checked += 1
+    assert checked == len(want)
+
+
+def test_reduction_operators_match_torch():
+    from mlx8_ws_audio_transformer_amd import urbansound_classifier as uc
+    g = torch.Generator().manual_seed(3)
+    for M, d in [(1, 4), (700, 128), (1030, 10), (513, 1280)]:
+        a = torch.randn(M, d, generator=g).cuda()
+        np.testing.assert_allclose(uc._column_sums(a).cpu().numpy(), a.double().sum(0).float().cpu().numpy(), rtol=2e-5, atol=2e-5)
+    x = (torch.randn(700, 128, generator=g) * 3 + 1).cuda().requires_grad_(True)
+    gam, bet = torch.randn(128, generator=g).cuda().requires_grad_(True), torch.randn(128, generator=g).cuda().requires_grad_(True)
+    dy = torch.randn(700, 128, generator=g).cuda()
+    uc._LayerNorm.apply(x, gam, bet, 1e-5).backward(dy)
+    got = (x.grad.clone(), gam.grad.clone(), bet.grad.clone())
+    x64, g64, b64 = (t.detach().double().requires_grad_(True) for t in (x, gam, bet))
+    torch.nn.functional.layer_norm(x64, (128,), g64, b64, 1e-5).backward(dy.double())
+    for a, b in zip(got, (x64.grad, g64.grad, b64.grad)):
+        np.testing.assert_allclose(a.cpu().numpy(), b.float().cpu().numpy(), rtol=1e-4, atol=2e-4)
+
+
+def test_train_transformer_learns_a_separable_toy_problem_and_matches_one_adam_step():
+    """`train_transformer` over the native operators: (1) after ONE batch the updated weights equal a torch Adam step on the reference
+    module (dropout 0); (2) with the reference's dropout 0.1 the loss on a two-class toy set drops well below ln 2."""
+    from mlx8_ws_audio_transformer_amd.urbansound_classifier import TransformerUrbanSound8KClassifier, train_transformer
+    ref, nat = _train_pair(64, 126, seed=11)
+    x = torch.from_numpy(wts.unit_variates("cls.xa", 4 * 64 * 126, 9).reshape(4, 64, 126).astype(np.float32)) * 2.0 - 4.0
+    y = torch.tensor([0, 3, 3, 9])
+    opt = torch.optim.Adam(ref.parameters(), lr=1e-3)
+    torch.nn.CrossEntropyLoss()(ref(x), y).backward(); opt.step()
+    train_transformer([(x, y)], model=nat, epochs=1, lr=1e-3)
+    want = dict(ref.named_parameters())
+    for name, p in nat.named_parameters():
+        # Adam's first step moves every weight by ~lr * sign(grad): compare the moved weights, tolerating sign flips of gradients at noise level
+        diff = (p.detach().cpu() - want[name].detach()).abs()
+        assert float((diff > 2.5e-4).float().mean()) < 2e-3, (name, float(diff.max()))
+
+    torch.manual_seed(0)
+    model = TransformerUrbanSound8KClassifier(n_classes=2, n_mels=64).cuda()
+    gen = torch.Generator().manual_seed(1)
+    def batch():
+        yb = torch.randint(0, 2, (16,), generator=gen)
+        xb = torch.randn(16, 64, 62, generator=gen) * 0.5 - 4.0
+        xb[yb == 1, 10:20, :] += 2.0                     # class 1: a brighter band of mel bins
+        return xb, yb
+    data = [batch() for _ in range(40)]
+    model, losses = train_transformer(data, model=model, epochs=3, lr=1e-3)
+    assert losses[0] > losses[-1] and losses[-1] < 0.2, losses
+    model.eval()
+    xb, yb = batch()
+    assert float((model(xb.cuda()).argmax(-1).cpu() == yb).float().mean()) >= 0.9
