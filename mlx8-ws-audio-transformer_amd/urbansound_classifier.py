@@ -292,7 +292,7 @@ def train_transformer(train_loader, model: Optional[TransformerUrbanSound8KClass
             loss = native_cross_entropy(logits, yb)
             loss.backward()
             optimizer.step()
-            total += float(loss) * xb.size(0)
+            total += float(loss.detach()) * xb.size(0)
             seen += xb.size(0)
         losses.append(total / max(seen, 1))
         if log is not None:

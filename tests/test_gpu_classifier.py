@@ -64,7 +64,7 @@ def test_training_step_gradients_match_autograd_of_the_reference_module(n_mels, 
     want_loss.backward()
     got_loss = native_cross_entropy(nat(x.cuda()), y.cuda())
     got_loss.backward()
-    assert abs(float(got_loss) - float(want_loss)) < 1e-4
+    assert abs(float(got_loss.detach()) - float(want_loss.detach())) < 1e-4
     want = dict(ref.named_parameters())
     checked = 0
     for name, p in nat.named_parameters():
@@ -107,9 +107,12 @@ def test_train_transformer_learns_a_separable_toy_problem_and_matches_one_adam_s
     train_transformer([(x, y)], model=nat, epochs=1, lr=1e-3)
     want = dict(ref.named_parameters())
     for name, p in nat.named_parameters():
-        # Adam's first step moves every weight by ~lr * sign(grad): compare the moved weights, tolerating sign flips of gradients at noise level
-        diff = (p.detach().cpu() - want[name].detach()).abs()
-        assert float((diff > 2.5e-4).float().mean()) < 2e-3, (name, float(diff.max()))
+        # Adam's first step moves every weight by ~lr * sign(grad): compare the moved weights where the gradient is above noise level
+        # (the key bias has an analytically zero gradient -- softmax is invariant to it -- so its update is the sign of rounding noise)
+        g = want[name].grad.abs()
+        live = g > 1e-3 * g.max()
+        diff = (p.detach().cpu() - want[name].detach()).abs()[live]
+        assert diff.numel() > 0 and float(diff.max()) < 2.5e-4, (name, float(diff.max()))
 
     torch.manual_seed(0)
     model = TransformerUrbanSound8KClassifier(n_classes=2, n_mels=64).cuda()
