@@ -27,8 +27,13 @@ def test_create_rejects_unsupported_configs():
     assert rc == -1 and b"head_dim" in L.awt_last_error()
     rc, _ = _create(wts.config("mini"), terms=2)
     assert rc == -1 and b"mfma_terms" in L.awt_last_error()
-    rc, _ = _create(wts.config("mini"), r=8, alpha=16.0, targets=_lib.LORA_BITS["fc1"], training=1)
-    assert rc == -1 and b"q_proj / k_proj / v_proj" in L.awt_last_error()
+    rc, _ = _create(wts.config("mini"), terms=5, r=8, alpha=16.0, targets=_lib.LORA_BITS["fc1"], training=1)   # f16f8 is inference-only
+    assert rc == -1 and b"mfma_terms must be 1 or 3" in L.awt_last_error()
+    rc, _ = _create(wts.config("mini"), training=1)                                                              # nothing to train
+    assert rc == -1 and b"needs adapters" in L.awt_last_error()
+    rc, h = _create(wts.config("mini"), r=8, alpha=16.0, targets=_lib.LORA_BITS["fc1"], training=1)              # every target trains
+    assert rc == 0
+    L.awt_encoder_destroy(h)
 
 
 def test_set_weight_and_forward_state_errors():

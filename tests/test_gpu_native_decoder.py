@@ -137,7 +137,7 @@ def test_native_decoder_gradients_match_the_torch_decoder():
                     p.copy_(torch.from_numpy(0.05 * wts.unit_variates("ndec", p.numel(), 1).reshape(p.shape).astype(np.float32)))
         out = model(input_features=mel, labels=labels)
         out.loss.backward()
-        res[native] = (float(out.loss), torch.cat([p.grad.flatten() for p in model.lora_parameters()]).cpu(), out.logits.float().cpu())
+        res[native] = (float(out.loss.detach()), torch.cat([p.grad.flatten() for p in model.lora_parameters()]).cpu(), out.logits.float().cpu())
     assert abs(res[True][0] - res[False][0]) < 2e-4 * abs(res[False][0])
     assert float((res[True][2] - res[False][2]).abs().max()) < 2e-3
     ref = res[False][1]
