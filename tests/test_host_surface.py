@@ -65,15 +65,16 @@ def test_synth_follows_reference_distributions():
     assert synth.note_number_to_name(69) == "A4" and synth.note_number_to_name(21) == "A0"
 
 
-def test_classifier_keeps_reference_parameter_names_and_refuses_to_train():
+def test_classifier_keeps_reference_parameter_names_and_has_no_cpu_fallback():
     import pytest
     from mlx8_ws_audio_transformer_amd.urbansound_classifier import TransformerUrbanSound8KClassifier
     from oracle.urbansound_classifier import ReferenceTransformerClassifier
     nat, ref = TransformerUrbanSound8KClassifier(n_mels=80), ReferenceTransformerClassifier(n_mels=80)
     assert list(nat.state_dict()) == list(ref.state_dict())            # a reference checkpoint loads with load_state_dict
     assert {k: tuple(v.shape) for k, v in nat.state_dict().items()} == {k: tuple(v.shape) for k, v in ref.state_dict().items()}
-    with pytest.raises(NotImplementedError):
-        nat.train()(torch.zeros(1, 80, 126))
+    for mode in (nat.train(), nat.eval()):                              # both paths are libawt calls: CPU tensors are refused, not routed to torch
+        with pytest.raises(ValueError, match="cuda device"):
+            mode(torch.zeros(1, 80, 126))
     with pytest.raises(ValueError):
         TransformerUrbanSound8KClassifier(dim=128, heads=1)            # head_dim 128 > the kernel's 64
 
