@@ -320,7 +320,7 @@ __global__ __launch_bounds__(64 * NW, (QT == 1 && NW == 6) ? 3 : 2) void attenti
 // One 32-query tile per wave (the second accumulator tile takes the registers of the second query tile), four waves.
 // K (or V) planes of tile kt -> stage: 8 groups of 64 sixteen-byte slots in the fp16 plane, 4 in each e4m3 plane.  Four waves: two
 // fp16 groups and one group of each e4m3 plane per wave; eight waves: one fp16 group and one e4m3 group (waves 0-3 hi8, 4-7 lo8).
-template <int NW, bool ISK>
+template <int NW, bool ISK, bool W8 = true>
 __device__ __forceinline__ void stage_kv1(const Attn8Args& a, int64_t head_off, int kt, char* stage, int wave, int lane) {
   const int64_t tile_off = head_off + (int64_t)kt * (KB * 64);
   const int last = a.S - 1 - kt * KB;
@@ -333,6 +333,7 @@ __device__ __forceinline__ void stage_kv1(const Attn8Args& a, int64_t head_off, 
     const int p = (g0 + wave) * 64 + lane, row = p >> 3;
     glds16(p16 + (unsigned)(min(row, last) * 64 + (((p & 7) ^ swz16(row)) << 3)), stage + O16 + (g0 + wave) * 1024);
   }
+  if constexpr (!W8) return;          // fp16-only operand (V of the single-product P V): no e4m3 planes to stage
   const int grp = wave & 3;
   const int p = grp * 64 + lane, row = p >> 2;
   const unsigned off = (unsigned)(min(row, last) * 64 + (((p & 3) ^ (ISK ? swz_k8(row) : swz_v8(row))) << 4));
@@ -344,7 +345,7 @@ __device__ __forceinline__ void stage_kv1(const Attn8Args& a, int64_t head_off, 
   }
 }
 
-template <int NW>
+template <int NW, bool PV8>
 __global__ __launch_bounds__(64 * NW, 2) void attention_f16f8_pipe_kernel(Attn8Args a) {
   constexpr int QB = 32 * NW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -397,7 +398,9 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f16f8_pipe_kernel(Attn8A
   //   slots  0..11  S(kt + 1)^T = K Q^T: per 32-key sub-tile the two e4m3 cross terms, then the four fp16 k-steps
   //   slots 12..19  O^T += V16^T P16^T  (kt2, s2, et)
   //   slots 20..23  O^T += V8^T Pl8^T + Vl8^T P8^T  (et x 2)
-  constexpr int NSLOT = 24, DEPTH = 2;
+  //                 (PV8 only; without it P V is the single fp16 product: P in [0, 1] rounds to 11 significant bits and the
+  //                  normaliser is the sum of the unrounded P -- DESIGN.md "Numerics" for what that costs)
+  constexpr int NSLOT = PV8 ? 24 : 20, DEPTH = 2;
   auto read_slot = [&](auto slot_t, const char* kst, const char* vst, i32x8& f) {
     constexpr int SLOT = decltype(slot_t)::value;
     if constexpr (SLOT < 12) {
@@ -429,7 +432,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f16f8_pipe_kernel(Attn8A
 
   // prologue: K(0), V(0) -> stage 0, K(1) -> stage 1; S(0)
   stage_kv1<NW, true>(a, head_off, 0, smem, wave, lane);
-  stage_kv1<NW, false>(a, head_off, 0, smem, wave, lane);
+  stage_kv1<NW, false, PV8>(a, head_off, 0, smem, wave, lane);
   if (ntiles > 1) stage_kv1<NW, true>(a, head_off, 1, smem + STAGE, wave, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -464,7 +467,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f16f8_pipe_kernel(Attn8A
 #ifndef AWT_DIAG8_NO_STAGE   // AWT_DIAG8_*: timing-only builds (tools/build_attn8_variants.sh), wrong results, never shipped
     if constexpr (!LAST) {
       if (kt + 2 < ntiles) stage_kv1<NW, true>(a, head_off, kt + 2, const_cast<char*>(cur), wave, lane);
-      stage_kv1<NW, false>(a, head_off, kt + 1, const_cast<char*>(oth), wave, lane);
+      stage_kv1<NW, false, PV8>(a, head_off, kt + 1, const_cast<char*>(oth), wave, lane);
     }
 #endif
     bf16x8 p16[4];
@@ -502,7 +505,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f16f8_pipe_kernel(Attn8A
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[et][r] *= alpha;
         if constexpr (et == 1) l_run = l_run * alpha + psum;
-      } else if constexpr (C < 20) {               // four accumulator registers -> one dword of each e4m3 operand
+      } else if constexpr (C < 20 && PV8) {        // four accumulator registers -> one dword of each e4m3 operand
         constexpr int I = C - 12, c2 = I >> 2, r4 = I & 3;
         float lo[4];
 #pragma unroll
@@ -587,13 +590,13 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f16f8_pipe_kernel(Attn8A
   }
 }
 
-template <int NW>
+template <int NW, bool PV8>
 int launch_pipe(const Attn8Args& a, hipStream_t s) {
   constexpr int lds = 2 * STAGE;
   constexpr int QB = 32 * NW;
-  AWT_ONCE_PER_DEVICE(AWT_HIP_CHECK(hipFuncSetAttribute((const void*)attention_f16f8_pipe_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)));
+  AWT_ONCE_PER_DEVICE(AWT_HIP_CHECK(hipFuncSetAttribute((const void*)attention_f16f8_pipe_kernel<NW, PV8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)));
   dim3 grid(((a.S + QB - 1) / QB) * a.B * a.H);
-  hipLaunchKernelGGL(attention_f16f8_pipe_kernel<NW>, grid, dim3(64 * NW), lds, s, a);
+  hipLaunchKernelGGL((attention_f16f8_pipe_kernel<NW, PV8>), grid, dim3(64 * NW), lds, s, a);
   AWT_HIP_CHECK(hipGetLastError());
   return AWT_OK;
 }
@@ -622,17 +625,24 @@ int launch_attention_f16f8(awt_ctx* c, const F8Planes& q, const F8Planes& k, con
   Attn8Args a{q.p16, k.p16, v.p16, q.hi8, q.lo8, k.hi8, k.lo8, v.hi8, v.lo8, o.p16, o.hi8, o.lo8, o_f32, lse, B, H, S};
   ProfScope prof(c, AWT_PROF_ATTENTION, s, 4.0 * (double)B * H * (double)S * S * 64);
   // shapes (awt_tuning_set "attn_shape"): 0 = auto; 1 = 4 waves x 32 queries; 2 = 4 waves x 64 queries; 3 = 6 waves x 32 queries
-  // (three waves per SIMD: one wave's softmax VALU work runs beside the others' MFMAs)
+  // (three waves per SIMD: one wave's softmax VALU work runs beside the others' MFMAs); 4 / 5 = software-pipelined, 4 / 8 waves,
+  // every cross term; 6 / 7 = the same with P V as one fp16 product
   const int shape = g_attn_shape;
   if (shape == 1) return launch_t<1, 4>(a, s);
   if (shape == 2) return launch_t<2, 4>(a, s);
   if (shape == 3) return launch_t<1, 6>(a, s);
-  if (shape == 4) return launch_pipe<4>(a, s);
-  if (shape == 5) return launch_pipe<8>(a, s);
-  // measured at B = 64, H = 12, S = 1500 (tools/attn_bench.py): plain 4 x 32 queries 1.25 ms, 4 x 64 queries 1.40 ms (70 spilled
-  // registers), 6 x 32 queries 1.67 ms; software-pipelined 4 x 32 queries 1.15 ms, 8 x 32 queries (one workgroup per CU, half the
-  // K / V staging traffic) 1.13 ms.  Small grids take the four-wave form (twice the workgroups).
+  if (shape == 4) return launch_pipe<4, true>(a, s);
+  if (shape == 5) return launch_pipe<8, true>(a, s);
+  if (shape == 6) return launch_pipe<4, false>(a, s);
+  if (shape == 7) return launch_pipe<8, false>(a, s);
+  // measured at B = 64, H = 12, S = 1500 (tools/attn_bench.py, profiles/r02_attention_shapes.txt): plain 4 x 32 queries 1.28 ms,
+  // 4 x 64 queries 1.44 ms (70 spilled registers), 6 x 32 queries 1.68 ms; software-pipelined 4 x 32 queries 1.16 ms, 8 x 32 queries
+  // 1.19 ms; pipelined with the single fp16 product for P V (shapes 6 / 7): 0.82 / 0.86 ms.  The kernel is VALU-bound (33 v_exp_f32 +
+  // ~260 other VALU instructions against 24 MFMAs per wave and key tile), so dropping the two e4m3 cross terms of P V -- their
+  // P_lo = P - fp16(P) arithmetic and e4m3 packing is 40 % of that VALU work -- is what buys the time.  Cost: P and V enter that
+  // product with 11 significant bits (error <= 2^-12 |v|_max per output against 2^-15); q k^T keeps its cross terms because an
+  // error in a logit is amplified by exp.  Small grids take the four-wave form (twice the workgroups).
   const int64_t wg8 = (int64_t)((S + 255) / 256) * B * H;
-  if (wg8 >= 256) return launch_pipe<8>(a, s);
-  return launch_pipe<4>(a, s);
+  if (lse) return wg8 >= 256 ? launch_pipe<8, true>(a, s) : launch_pipe<4, true>(a, s);   // training keeps every cross term
+  return launch_pipe<4, false>(a, s);      // 4 waves beat 8 here (0.82 vs 0.86 ms): two workgroups per CU drift apart, which is what lets VALU and MFMA phases overlap
 }

@@ -51,7 +51,7 @@ extern "C" int awt_tuning_set(const char* key, int value) {
     return AWT_OK;
   }
   if (!strcmp(key, "attn_shape")) {
-    AWT_REQUIRE(value >= 0 && value <= 5, AWT_ERR_INVALID, "tuning_set: attn_shape must be 0 (auto) or 1 .. 5");
+    AWT_REQUIRE(value >= 0 && value <= 9, AWT_ERR_INVALID, "tuning_set: attn_shape must be 0 (auto) or 1 .. 9");
     awt_attn_force_shape(value);
     return AWT_OK;
   }

@@ -62,7 +62,10 @@ def test_layernorm(d):
 
 
 # max-abs error bound of softmax(q k^T) v vs float64 on these inputs, per operand precision
-ATT_TOL = {"bf16x3": 1e-4, "fp16x3": 2e-5, "f16f8": 2e-4, "bf16": 4e-2}
+# f16f8: q k^T with every cross term (2^-15 per logit), P V as one fp16 product (11-bit P and V: <= 2^-12 |v|_max ~ 1e-3 for N(0, 1) values);
+# the kernel variants that keep P V's e4m3 cross terms (attn_shape 1 .. 5) stay within 2e-4
+ATT_TOL = {"bf16x3": 1e-4, "fp16x3": 2e-5, "f16f8": 2e-3, "bf16": 4e-2}
+ATT_TOL_F16F8_CROSS = 2e-4
 
 
 @pytest.mark.parametrize("precision", ["bf16x3", "bf16", "fp16x3", "f16f8"])
@@ -78,7 +81,7 @@ def test_attention(precision, B, H, S):
     assert err < ATT_TOL[precision], err  # v_exp_f32 ~1 ulp; bf16 rounds q, k, v and P
 
 
-@pytest.mark.parametrize("shape", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("shape", [1, 2, 3, 4, 5, 6, 7])
 def test_attention_f16f8_workgroup_shapes(shape):
     """Every workgroup shape of the f16f8 attention kernel (4 x 32, 4 x 64, 6 x 32 queries) on a sequence with a tail tile."""
     from mlx8_ws_audio_transformer_amd import _lib, ops
@@ -92,7 +95,7 @@ def test_attention_f16f8_workgroup_shapes(shape):
             _lib.tuning_set("attn_shape", 0)
         p = torch.softmax(q.double() @ k.double().transpose(2, 3), dim=-1)
         ref = (p @ v.double()).transpose(1, 2).reshape(B, S, H * 64)
-        assert (o.double() - ref).abs().max().item() < ATT_TOL["f16f8"], S
+        assert (o.double() - ref).abs().max().item() < (ATT_TOL_F16F8_CROSS if shape <= 5 else ATT_TOL["f16f8"]), S
 
 
 @pytest.mark.parametrize("precision", ["bf16x3", "fp16x3", "f16f8", "f16f8-pipe"])
