@@ -441,14 +441,39 @@ __global__ __launch_bounds__(64) void small_attn_dkv_kernel(SmallAttn a) {
   const int h = bh % a.H, b = bh / a.H;
   const bool live = j < a.Sk;
   const int jj = live ? j : a.Sk - 1;
-  const float* kr = a.k + ((int64_t)b * a.Sk + jj) * a.ldk + 64 * h;
-  const float* vr = a.v + ((int64_t)b * a.Sk + jj) * a.ldv + 64 * h;
+  // The lane owns key j, but global memory wants a row's 64 dims on neighbouring lanes: tiles go through a padded LDS patch
+  // (row pitch 65 words: conflict-free both ways), 16 lanes x float4 per 256-byte row, four rows per instruction.
+  __shared__ float tile[64][65];
+  const int j0 = (blockIdx.x % chunks) * 64, tr = lane >> 4, tc = (lane & 15) * 4;
+  (void)jj;
   float k[64], v[64], dk[64], dv[64];
+  auto load_tile = [&](const float* base, int ld, float (&dst)[64]) {
+    __syncthreads();
 #pragma unroll
-  for (int e = 0; e < 64; e += 4) {
-    const float4 t = *reinterpret_cast<const float4*>(kr + e), u = *reinterpret_cast<const float4*>(vr + e);
-    k[e] = t.x; k[e + 1] = t.y; k[e + 2] = t.z; k[e + 3] = t.w; v[e] = u.x; v[e + 1] = u.y; v[e + 2] = u.z; v[e + 3] = u.w;
-  }
+    for (int r0 = 0; r0 < 64; r0 += 4) {
+      const int r = min(j0 + r0 + tr, a.Sk - 1);
+      const float4 t = *reinterpret_cast<const float4*>(base + ((int64_t)b * a.Sk + r) * ld + 64 * h + tc);
+      tile[r0 + tr][tc] = t.x; tile[r0 + tr][tc + 1] = t.y; tile[r0 + tr][tc + 2] = t.z; tile[r0 + tr][tc + 3] = t.w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 64; ++e) dst[e] = tile[lane][e];
+  };
+  auto store_tile = [&](float* base, int ld, const float (&src)[64]) {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 64; ++e) tile[lane][e] = src[e];
+    __syncthreads();
+#pragma unroll
+    for (int r0 = 0; r0 < 64; r0 += 4) {
+      const int r = j0 + r0 + tr;
+      if (r < a.Sk)
+        *reinterpret_cast<float4*>(base + ((int64_t)b * a.Sk + r) * ld + 64 * h + tc) =
+            make_float4(tile[r0 + tr][tc], tile[r0 + tr][tc + 1], tile[r0 + tr][tc + 2], tile[r0 + tr][tc + 3]);
+    }
+  };
+  load_tile(a.k, a.ldk, k);
+  load_tile(a.v, a.ldv, v);
 #pragma unroll
   for (int e = 0; e < 64; ++e) { dk[e] = 0.f; dv[e] = 0.f; }
   const int i0 = a.causal ? max(0, j - a.causal_off) : 0;         // first query row that sees this key
@@ -474,14 +499,8 @@ __global__ __launch_bounds__(64) void small_attn_dkv_kernel(SmallAttn a) {
       dv[e] += p * u.x; dv[e + 1] += p * u.y; dv[e + 2] += p * u.z; dv[e + 3] += p * u.w;
     }
   }
-  if (!live) return;
-  float* dkr = a.dk + ((int64_t)b * a.Sk + j) * a.ldk + 64 * h;
-  float* dvr = a.dv + ((int64_t)b * a.Sk + j) * a.ldv + 64 * h;
-#pragma unroll
-  for (int e = 0; e < 64; e += 4) {
-    *reinterpret_cast<float4*>(dkr + e) = make_float4(dk[e], dk[e + 1], dk[e + 2], dk[e + 3]);
-    *reinterpret_cast<float4*>(dvr + e) = make_float4(dv[e], dv[e + 1], dv[e + 2], dv[e + 3]);
-  }
+  store_tile(a.dk, a.ldk, dk);
+  store_tile(a.dv, a.ldv, dv);
 }
 
 int check_small(const SmallAttn& a, const char* who) {
