@@ -320,14 +320,17 @@ __global__ __launch_bounds__(64 * NW, (QT == 1 && NW == 6) ? 3 : 2) void attenti
 // One 32-query tile per wave (the second accumulator tile takes the registers of the second query tile), four waves.
 // K (or V) planes of tile kt -> stage: 8 groups of 64 sixteen-byte slots in the fp16 plane, 4 in each e4m3 plane.  Four waves: two
 // fp16 groups and one group of each e4m3 plane per wave; eight waves: one fp16 group and one e4m3 group (waves 0-3 hi8, 4-7 lo8).
-template <int NW, bool ISK, bool W8 = true>
+// RING3 (the single-product P V form): `stage` is the tile's own slot of a three-deep ring -- K slots [K16 | K8 | Klo8] of 16 KB, V slots
+// [V16] of 8 KB -- instead of a 32 KB stage shared by K and V.
+constexpr int K3_SLOT = PL16 + 2 * PL8, V3_SLOT = PL16, K3_O8 = PL16, K3_OL8 = PL16 + PL8, V3_BASE = 3 * K3_SLOT, RING3_BYTES = 3 * (K3_SLOT + V3_SLOT);
+template <int NW, bool ISK, bool W8 = true, bool RING3 = false>
 __device__ __forceinline__ void stage_kv1(const Attn8Args& a, int64_t head_off, int kt, char* stage, int wave, int lane) {
   const int64_t tile_off = head_off + (int64_t)kt * (KB * 64);
   const int last = a.S - 1 - kt * KB;
   const bf16_t* p16 = (ISK ? a.k16 : a.v16) + tile_off;
   const uint8_t* p8 = (ISK ? a.k8 : a.v8) + tile_off;
   const uint8_t* pl8 = (ISK ? a.kl8 : a.vl8) + tile_off;
-  constexpr int O16 = ISK ? OFF_K16 : OFF_V16, O8 = ISK ? OFF_K8 : OFF_V8, OL8 = ISK ? OFF_KL8 : OFF_VL8;
+  constexpr int O16 = RING3 ? 0 : (ISK ? OFF_K16 : OFF_V16), O8 = RING3 ? K3_O8 : (ISK ? OFF_K8 : OFF_V8), OL8 = RING3 ? K3_OL8 : (ISK ? OFF_KL8 : OFF_VL8);
 #pragma unroll
   for (int g0 = 0; g0 < 8; g0 += NW) {
     const int p = (g0 + wave) * 64 + lane, row = p >> 3;
@@ -401,16 +404,23 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f16f8_pipe_kernel(Attn8A
   //                 (PV8 only; without it P V is the single fp16 product: P in [0, 1] rounds to 11 significant bits and the
   //                  normaliser is the sum of the unrounded P -- DESIGN.md "Numerics" for what that costs)
   constexpr int NSLOT = PV8 ? 24 : 20, DEPTH = 2;
+  // LDS: PV8 -- two 32 KB stages shared by K and V (K staged two tiles ahead, V one).  !PV8 -- three-deep rings (K three tiles ahead,
+  // V two): a tile's LDS-DMA then has two iterations (~4 us) to land instead of one, and the wait at the end of an iteration only covers
+  // the loads of the iteration before (counted vmcnt).  With one iteration of slack the timing-only build without the wait ran 18 % faster.
+  constexpr bool RING3 = !PV8;
+  constexpr int KO8 = RING3 ? K3_O8 : OFF_K8, KOL8 = RING3 ? K3_OL8 : OFF_KL8, VO16 = RING3 ? 0 : OFF_V16;
+  auto kslot = [&](int t) -> char* { return RING3 ? smem + (t % 3) * K3_SLOT : smem + (t & 1) * STAGE; };
+  auto vslot = [&](int t) -> char* { return RING3 ? smem + V3_BASE + (t % 3) * V3_SLOT : smem + (t & 1) * STAGE; };
   auto read_slot = [&](auto slot_t, const char* kst, const char* vst, i32x8& f) {
     constexpr int SLOT = decltype(slot_t)::value;
     if constexpr (SLOT < 12) {
       constexpr int kt2 = SLOT / 6, w = SLOT % 6;
       if constexpr (w < 2) {
-        const char* pl = kst + (w == 0 ? OFF_K8 : OFF_KL8) + kt2 * 2048;
+        const char* pl = kst + (w == 0 ? KO8 : KOL8) + kt2 * 2048;
         const uint4 x0 = *reinterpret_cast<const uint4*>(pl + k8off[0]), x1 = *reinterpret_cast<const uint4*>(pl + k8off[1]);
         f = (i32x8){(int)x0.x, (int)x0.y, (int)x0.z, (int)x0.w, (int)x1.x, (int)x1.y, (int)x1.z, (int)x1.w};
       } else {
-        const uint4 x0 = *reinterpret_cast<const uint4*>(kst + OFF_K16 + koff[w - 2] + kt2 * 4096);
+        const uint4 x0 = *reinterpret_cast<const uint4*>(kst + koff[w - 2] + kt2 * 4096);
         f[0] = (int)x0.x; f[1] = (int)x0.y; f[2] = (int)x0.z; f[3] = (int)x0.w;
       }
     } else if constexpr (SLOT < 20) {
@@ -418,7 +428,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f16f8_pipe_kernel(Attn8A
       constexpr int cst = kt2 * 4096 + s2 * 2048;
       const int off0 = (et == 0 ? voff : voffx) + cst;
       const int off1 = (et == 0 ? voffx : voff) + cst + 1024;
-      const i32x2 va = __builtin_bit_cast(i32x2, tr_read16(vst + OFF_V16 + off0)), vb = __builtin_bit_cast(i32x2, tr_read16(vst + OFF_V16 + off1));
+      const i32x2 va = __builtin_bit_cast(i32x2, tr_read16(vst + VO16 + off0)), vb = __builtin_bit_cast(i32x2, tr_read16(vst + VO16 + off1));
       f[0] = va[0]; f[1] = va[1]; f[2] = vb[0]; f[3] = vb[1];
     } else {
       constexpr int I = SLOT - 20, et = I >> 1, lo = I & 1;
@@ -431,9 +441,13 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f16f8_pipe_kernel(Attn8A
   };
 
   // prologue: K(0), V(0) -> stage 0, K(1) -> stage 1; S(0)
-  stage_kv1<NW, true>(a, head_off, 0, smem, wave, lane);
-  stage_kv1<NW, false, PV8>(a, head_off, 0, smem, wave, lane);
-  if (ntiles > 1) stage_kv1<NW, true>(a, head_off, 1, smem + STAGE, wave, lane);
+  stage_kv1<NW, true, true, RING3>(a, head_off, 0, kslot(0), wave, lane);
+  stage_kv1<NW, false, PV8, RING3>(a, head_off, 0, vslot(0), wave, lane);
+  if (ntiles > 1) stage_kv1<NW, true, true, RING3>(a, head_off, 1, kslot(1), wave, lane);
+  if constexpr (RING3) {
+    if (ntiles > 1) stage_kv1<NW, false, PV8, RING3>(a, head_off, 1, vslot(1), wave, lane);
+    if (ntiles > 2) stage_kv1<NW, true, true, RING3>(a, head_off, 2, kslot(2), wave, lane);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   f32x16 sa[2], sb[2];
@@ -448,11 +462,11 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f16f8_pipe_kernel(Attn8A
   };
   {
     i32x8 ring[3];
-    read_slot(std::integral_constant<int, 0>{}, smem, smem, ring[0]);
-    read_slot(std::integral_constant<int, 1>{}, smem, smem, ring[1]);
+    read_slot(std::integral_constant<int, 0>{}, kslot(0), vslot(0), ring[0]);
+    read_slot(std::integral_constant<int, 1>{}, kslot(0), vslot(0), ring[1]);
     [&]<int... I>(std::integer_sequence<int, I...>) {
       ([&] {
-        if constexpr (I + DEPTH < 12) read_slot(std::integral_constant<int, I + DEPTH>{}, smem, smem, ring[(I + DEPTH) % 3]);
+        if constexpr (I + DEPTH < 12) read_slot(std::integral_constant<int, I + DEPTH>{}, kslot(0), vslot(0), ring[(I + DEPTH) % 3]);
         qk_mma(std::integral_constant<int, I>{}, ring[I % 3], sa);
       }(), ...);
     }(std::make_integer_sequence<int, 12>{});
@@ -462,12 +476,17 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f16f8_pipe_kernel(Attn8A
   auto iter = [&](auto last_t, auto tail_t, int kt, f32x16 (&sc)[2], f32x16 (&sn)[2]) {
     constexpr bool LAST = decltype(last_t)::value, TAIL = decltype(tail_t)::value;
     constexpr int FIRST = LAST ? 12 : 0;                  // the last tile has no next scores to compute
-    const char* cur = smem + (kt & 1) * STAGE;            // V(kt) lives here; K(kt + 2) is staged here
-    const char* oth = smem + ((kt + 1) & 1) * STAGE;      // K(kt + 1) lives here; V(kt + 1) is staged here
+    const char* cur = vslot(kt);                          // V(kt)
+    const char* oth = kslot(kt + 1);                      // K(kt + 1)
 #ifndef AWT_DIAG8_NO_STAGE   // AWT_DIAG8_*: timing-only builds (tools/build_attn8_variants.sh), wrong results, never shipped
     if constexpr (!LAST) {
-      if (kt + 2 < ntiles) stage_kv1<NW, true>(a, head_off, kt + 2, const_cast<char*>(cur), wave, lane);
-      stage_kv1<NW, false, PV8>(a, head_off, kt + 1, const_cast<char*>(oth), wave, lane);
+      if constexpr (RING3) {                              // K(kt + 3) takes K(kt)'s slot, V(kt + 2) takes V(kt - 1)'s
+        if (kt + 3 < ntiles) stage_kv1<NW, true, true, true>(a, head_off, kt + 3, kslot(kt), wave, lane);
+        if (kt + 2 < ntiles) stage_kv1<NW, false, false, true>(a, head_off, kt + 2, vslot(kt + 2), wave, lane);
+      } else {                                            // K(kt + 2) takes K(kt)'s half of the stage, V(kt + 1) V(kt - 1)'s
+        if (kt + 2 < ntiles) stage_kv1<NW, true>(a, head_off, kt + 2, kslot(kt), wave, lane);
+        stage_kv1<NW, false, PV8>(a, head_off, kt + 1, vslot(kt + 1), wave, lane);
+      }
     }
 #endif
     bf16x8 p16[4];
@@ -495,7 +514,13 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f16f8_pipe_kernel(Attn8A
         constexpr int e = C - 2, kt2 = e >> 2, r4 = e & 3;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+#if defined(AWT_DIAG8_NO_SUB)
+          const float pv = __builtin_amdgcn_exp2f(sc[kt2][4 * r4 + j]);
+#elif defined(AWT_DIAG8_NO_EXP)
+          const float pv = sc[kt2][4 * r4 + j] - m_new;
+#else
           const float pv = __builtin_amdgcn_exp2f(sc[kt2][4 * r4 + j] - m_new);
+#endif
           sc[kt2][4 * r4 + j] = pv;
           psum += pv;
           p16[2 * kt2 + (r4 >> 1)][4 * (r4 & 1) + j] = (short)f32_to_f16(pv);
@@ -503,7 +528,11 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f16f8_pipe_kernel(Attn8A
       } else if constexpr (C < 12) {               // rescale of one output tile
         constexpr int et = C - 10;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[et][r] *= alpha;
+        for (int r = 0; r < 16; ++r) {
+#ifndef AWT_DIAG8_NO_SUB
+          oacc[et][r] *= alpha;
+#endif
+        }
         if constexpr (et == 1) l_run = l_run * alpha + psum;
       } else if constexpr (C < 20 && PV8) {        // four accumulator registers -> one dword of each e4m3 operand
         constexpr int I = C - 12, c2 = I >> 2, r4 = I & 3;
@@ -544,7 +573,16 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f16f8_pipe_kernel(Attn8A
       }(), ...);
     }(std::make_integer_sequence<int, NSLOT - FIRST>{});
 #ifndef AWT_DIAG8_NO_DMAWAIT
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (RING3 && !LAST) {
+      // only the loads of the PREVIOUS iteration have to have landed: this iteration issued NK (fp16 groups + e4m3 groups) K and NV V
+      // LDS-DMA instructions per wave (fewer near the end of the key range)
+      constexpr int NK = 8 / NW + (NW == 4 ? 2 : 1), NV = 8 / NW;
+      if (kt + 3 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NK + NV) : "memory");
+      else if (kt + 2 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NV) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
 #endif
     __syncthreads();
   };
@@ -592,7 +630,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f16f8_pipe_kernel(Attn8A
 
 template <int NW, bool PV8>
 int launch_pipe(const Attn8Args& a, hipStream_t s) {
-  constexpr int lds = 2 * STAGE;
+  constexpr int lds = PV8 ? 2 * STAGE : RING3_BYTES;
   constexpr int QB = 32 * NW;
   AWT_ONCE_PER_DEVICE(AWT_HIP_CHECK(hipFuncSetAttribute((const void*)attention_f16f8_pipe_kernel<NW, PV8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)));
   dim3 grid(((a.S + QB - 1) / QB) * a.B * a.H);

@@ -456,6 +456,18 @@ __device__ __forceinline__ bf16x8 gload16(unsigned voff, const void* sbase) {
   return v;
 }
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// LDS fragment reads with hand-counted waits.  With the inline-asm global loads in the loop the compiler's own waitcnt insertion fell
+// back to s_waitcnt lgkmcnt(0) in front of every consumer (disassembly), i.e. every prefetched fragment waited for the youngest read
+// as well.  lds_read16 issues the read, lgkm_wait<N>(frag) waits until at most N younger LDS operations are outstanding; taking the
+// fragment as an in/out operand is what orders its consumers behind the wait.
+template <int OFF>
+__device__ __forceinline__ bf16x8 lds_read16(unsigned addr) {
+  bf16x8 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+template <int N> __device__ __forceinline__ void lgkm_wait(bf16x8& f) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(N)); }
+template <int N> __device__ __forceinline__ void lgkm_wait(bf16x8& f0, bf16x8& f1) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f0), "+v"(f1) : "n"(N)); }
 __device__ __forceinline__ i32x8 cat8(bf16x8 lo, bf16x8 hi) {
   return __builtin_shufflevector(__builtin_bit_cast(i32x4_t, lo), __builtin_bit_cast(i32x4_t, hi), 0, 1, 2, 3, 4, 5, 6, 7);
 }
@@ -589,11 +601,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f8_kernel(GemmArgs g) {
 
   // A fragment offsets inside a stage: fp16 image row r, chunk (2 ks + half) ^ ((r >> 1) & 7); e4m3 images row r, chunks
   // (2 half + c) ^ ((r >> 2) & 3).  Row tile i adds a multiple of 32 rows, which leaves both swizzle terms unchanged.
-  int a16off[4], a8off[2];
+  // (kept as absolute LDS byte addresses in the CURRENT stage, flipped at the end of every K-tile; the row tile goes into the ds_read's
+  // immediate offset.  Unrolling the K loop by two to make the stage an immediate as well cost 600+ spilled registers.)
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)(smem);
+  unsigned a16a[4], a8a[2];
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) a16off[ks] = (wr * TM * 32 + r32) * 128 + (((2 * ks + half) ^ ((r32 >> 1) & 7)) << 4);
+  for (int ks = 0; ks < 4; ++ks) a16a[ks] = lds0 + (wr * TM * 32 + r32) * 128 + (((2 * ks + half) ^ ((r32 >> 1) & 7)) << 4);
 #pragma unroll
-  for (int c = 0; c < 2; ++c) a8off[c] = PL16 + (wr * TM * 32 + r32) * 64 + (((2 * half + c) ^ ((r32 >> 2) & 3)) << 4);
+  for (int c = 0; c < 2; ++c) a8a[c] = lds0 + PL16 + (wr * TM * 32 + r32) * 64 + (((2 * half + c) ^ ((r32 >> 2) & 3)) << 4);
 
   constexpr int DMA_PER_STEP = (NDMA + TM - 1) / TM;    // every DMA piece is issued during k-step 0, ahead of all W reloads
   // One K-tile.  PF (compile time): prefetch K-tile kt + 1 (A by LDS-DMA into the other stage, W into the register ring).  The
@@ -601,44 +616,69 @@ __global__ __launch_bounds__(256, 2) void gemm_f8_kernel(GemmArgs g) {
   // epilogue has already reused (the compiler cannot see that an inline-asm load completes later).
   auto ktile = [&](auto pf_t, int kt) {
     constexpr bool PF = decltype(pf_t)::value;
-    const char* cur = smem + (kt & 1) * STAGE;
+    constexpr int STG = 0;                                // a16a / a8a already point into the current stage
     char* nxt = smem + ((kt + 1) & 1) * STAGE;
     if constexpr (PF) advance();        // from here on the streams point at K-tile kt + 1 (the W registers still hold K-tile kt)
-    // ---- fp16 part: k-step ks, row tile i: one 16-byte A fragment against the wave's TN weight fragments
-    bf16x8 af[2];
-    af[0] = *reinterpret_cast<const bf16x8*>(cur + a16off[0]);
+    // ---- fp16 part: k-step ks, row tile i: one 16-byte A fragment against the wave's TN weight fragments.  A step is only TN = 2
+    // MFMAs (64 matrix-pipe cycles) while an LDS read under load takes 100-150 cycles to return, so the fragments are read THREE steps
+    // ahead into a four-entry ring (one step ahead, every step stalled on its fragment: the disassembly showed s_waitcnt lgkmcnt(0)
+    // in front of every MFMA pair).
+    constexpr int AD = MULTI ? 1 : 3;   // the multi-segment form has no registers left for a deeper ring (it spilled)
+    bf16x8 af[AD + 1];
+    auto read_a16 = [&](auto s_t) {
+      constexpr int S2 = decltype(s_t)::value;
+      af[S2 % (AD + 1)] = lds_read16<STG * STAGE + (S2 % TM) * 32 * 128>(a16a[S2 / TM]);
+    };
+    [&]<int... S>(std::integer_sequence<int, S...>) { (read_a16(std::integral_constant<int, S>{}), ...); }(std::make_integer_sequence<int, AD>{});
+    // e4m3 part operands: X = hi8 image, Y = lo8 image of row tile i (two 16-byte reads each); X(i + 1) is read behind the X MFMAs of
+    // row tile i and lands while the Y MFMAs run (128 cycles), and vice versa: no extra registers, no exposed LDS latency after the
+    // first row tile, whose reads go out behind the last two fp16 steps (not in the multi-segment form: no registers left, it spilled).
+    bf16x8 ax[2], ay[2];
+    auto read_x = [&](auto i_t) { constexpr int O = STG * STAGE + decltype(i_t)::value * 32 * 64; ax[0] = lds_read16<O>(a8a[0]); ax[1] = lds_read16<O>(a8a[1]); };
+    auto read_y = [&](auto i_t) { constexpr int O = STG * STAGE + decltype(i_t)::value * 32 * 64 + PL8; ay[0] = lds_read16<O>(a8a[0]); ay[1] = lds_read16<O>(a8a[1]); };
+    constexpr bool EARLY8 = !MULTI;
     [&]<int... S>(std::integer_sequence<int, S...>) {
       ([&] {
         constexpr int ks = S / TM, i = S % TM;
-        if constexpr (S + 1 < 4 * TM) af[(S + 1) & 1] = *reinterpret_cast<const bf16x8*>(cur + a16off[(S + 1) / TM] + ((S + 1) % TM) * 32 * 128);
+        if constexpr (S + AD < 4 * TM) read_a16(std::integral_constant<int, S + AD>{});
+        if constexpr (EARLY8 && S == 4 * TM - 2) read_x(std::integral_constant<int, 0>{});
+        if constexpr (EARLY8 && S == 4 * TM - 1) read_y(std::integral_constant<int, 0>{});
         if constexpr (PF && ks == 0) {
           [&]<int... O>(std::integer_sequence<int, O...>) {
             ([&] { constexpr int op = i * DMA_PER_STEP + O; if constexpr (op < NDMA) dma(std::integral_constant<int, op>{}, nxt); }(), ...);
           }(std::make_integer_sequence<int, DMA_PER_STEP>{});
         }
+        // LDS operations younger than this step's fragment: the (up to) three fragments read ahead, plus the first e4m3 reads
+        constexpr int AHEAD = (4 * TM - 1 - S < AD ? 4 * TM - 1 - S : AD) + (EARLY8 && S >= 4 * TM - 2 ? 2 : 0) + (EARLY8 && S >= 4 * TM - 1 ? 2 : 0);
+        lgkm_wait<AHEAD>(af[S % (AD + 1)]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = mfma32<true>(af[S & 1], w16[ks][j], acc[i][j]);
+        for (int j = 0; j < TN; ++j) acc[i][j] = mfma32<true>(af[S % (AD + 1)], w16[ks][j], acc[i][j]);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (PF && i == TM - 1) load_w16(std::integral_constant<int, ks>{});     // ring: this k-step's registers, for K-tile kt + 1
       }(), ...);
     }(std::make_integer_sequence<int, 4 * TM>{});
     // ---- e4m3 part: its W registers were loaded a K-tile ago, behind this K-tile's NDMA + NW16 younger operations
     if constexpr (PF) wait_vm<NDMA + NW16>(); else wait_vm<0>();
+    if constexpr (!EARLY8) { read_x(std::integral_constant<int, 0>{}); read_y(std::integral_constant<int, 0>{}); }
+    [&]<int... I>(std::integer_sequence<int, I...>) {
+      ([&] {
+        lgkm_wait<2>(ax[0], ax[1]);                       // younger: Y(I)
+        __builtin_amdgcn_sched_barrier(0);
+        const i32x8 a8 = cat8(ax[0], ax[1]);
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const char* rowp = cur + i * 32 * 64;
-      const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(rowp + a8off[0]), x1 = *reinterpret_cast<const bf16x8*>(rowp + a8off[1]);
-      const bf16x8 y0 = *reinterpret_cast<const bf16x8*>(rowp + PL8 + a8off[0]), y1 = *reinterpret_cast<const bf16x8*>(rowp + PL8 + a8off[1]);
-      const i32x8 a8 = cat8(x0, x1), al8 = cat8(y0, y1);
-      __builtin_amdgcn_sched_barrier(0);
+        for (int j = 0; j < TN; ++j) acc[I][j] = mfma32_f8<e8m0(-kF8Act), e8m0(-kF8Wgt - kF8Lo)>(a8, cat8(wl8[j][0], wl8[j][1]), acc[I][j]);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (I + 1 < TM) read_x(std::integral_constant<int, I + 1>{});
+        lgkm_wait<(I + 1 < TM ? 2 : 0)>(ay[0], ay[1]);    // younger: X(I + 1)
+        __builtin_amdgcn_sched_barrier(0);
+        const i32x8 al8 = cat8(ay[0], ay[1]);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        acc[i][j] = mfma32_f8<e8m0(-kF8Act), e8m0(-kF8Wgt - kF8Lo)>(a8, cat8(wl8[j][0], wl8[j][1]), acc[i][j]);
-        acc[i][j] = mfma32_f8<e8m0(-kF8Act - kF8Lo), e8m0(-kF8Wgt)>(al8, cat8(w8[j][0], w8[j][1]), acc[i][j]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
+        for (int j = 0; j < TN; ++j) acc[I][j] = mfma32_f8<e8m0(-kF8Act - kF8Lo), e8m0(-kF8Wgt)>(al8, cat8(w8[j][0], w8[j][1]), acc[I][j]);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (I + 1 < TM) read_y(std::integral_constant<int, I + 1>{});
+      }(), ...);
+    }(std::make_integer_sequence<int, TM>{});
     if constexpr (PF) {
       load_w8();
       // the DMA pieces and the fp16 W fragments of K-tile kt + 1 are older than the NW8 e4m3 loads just issued
@@ -646,6 +686,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f8_kernel(GemmArgs g) {
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    if constexpr (PF) {
+      const int flip = (kt & 1) ? -STAGE : STAGE;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) a16a[ks] += flip;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) a8a[c] += flip;
+    }
   };
   for (int kt = 0; kt + 1 < ktiles; ++kt) ktile(std::true_type{}, kt);
   ktile(std::false_type{}, ktiles - 1);

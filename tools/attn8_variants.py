@@ -6,7 +6,7 @@ import torch
 from mlx8_ws_audio_transformer_amd import _lib, ops
 B, H, S = 64, 12, 1500
 q, k, v = (torch.randn(B, H, S, 64, device="cuda") for _ in range(3)); q *= 0.35
-for shape in (4, 1):
+for shape in (6, 4):
     _lib.tuning_set("attn_shape", shape)
     ops.attention(q, k, v, "f16f8")
     _lib.prof_enable(True, ["attention"]); _lib.prof_collect("attention")
