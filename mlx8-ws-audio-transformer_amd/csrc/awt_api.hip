@@ -41,7 +41,7 @@ void awt_prof_end(awt_ctx* c, int klass, hipStream_t s) {
 extern "C" int awt_tuning_set(const char* key, int value) {
   AWT_REQUIRE(key, AWT_ERR_INVALID, "tuning_set: null key");
   if (!strcmp(key, "gemm_tile")) {
-    AWT_REQUIRE(value == 0 || value == 64 || value == 128 || value == 256, AWT_ERR_INVALID, "tuning_set: gemm_tile must be 0 (auto), 64, 128 or 256");
+    AWT_REQUIRE(value == 0 || value == 64 || value == 128 || value == 256 || value == 512, AWT_ERR_INVALID, "tuning_set: gemm_tile must be 0 (auto), 64, 128, 256 or 512");
     awt_gemm_force_tile(value);
     return AWT_OK;
   }

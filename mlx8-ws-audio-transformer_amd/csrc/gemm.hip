@@ -448,6 +448,12 @@ __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, 2) void gemm_kernel(GemmArg
 // unused) so that the loop body has no branches.
 struct CfgF8W4 { static constexpr int WM = 1, WN = 4, TM = 4, TN = 2; };     // 128 x 256
 struct CfgF8Sq { static constexpr int WM = 2, WN = 2, TM = 2, TN = 2; };     // 128 x 128
+// 256 x 256 on 8 waves (one workgroup per CU): two 128 x 256 halves that share nothing in LDS, only the W fragment loads -- the two wave
+// rows request the same weight bytes within a few cycles of each other, so the second request is served by the CU's vector L1 and the
+// L2 -> CU traffic per output tile drops from 96 KB to 64 KB per 128 x 256 x 64 of work.  Measured (tools/gemm_tile_sweep.py,
+// profiles/r02_gemm_tile_sweep.txt): bit-identical results, 2 - 15 % SLOWER than two independent 128 x 256 workgroups per CU (all eight
+// waves meet at one barrier per K-tile), so it is not selected automatically; awt_tuning_set("gemm_tile", 512) runs it.
+struct CfgF8Big { static constexpr int WM = 2, WN = 4, TM = 4, TN = 2; };
 
 template <int OFF>
 __device__ __forceinline__ bf16x8 gload16(unsigned voff, const void* sbase) {
@@ -473,12 +479,12 @@ __device__ __forceinline__ i32x8 cat8(bf16x8 lo, bf16x8 hi) {
 }
 
 template <int EPI, class CFG, bool MULTI>
-__global__ __launch_bounds__(256, 2) void gemm_f8_kernel(GemmArgs g) {
+__global__ __launch_bounds__(CFG::WM * CFG::WN * 64, CFG::WM * CFG::WN == 4 ? 2 : 1) void gemm_f8_kernel(GemmArgs g) {
   constexpr int WM = CFG::WM, WN = CFG::WN, TM = CFG::TM, TN = CFG::TN;
-  constexpr int BM = WM * TM * 32, BN = WN * TN * 32, BK = 64;
-  static_assert(BM == 128 && WM * WN == 4, "128-row block tiles on four waves");
-  constexpr int PL16 = BM * BK * 2, PL8 = BM * BK, STAGE = PL16 + 2 * PL8;     // 16 + 8 + 8 KB
-  constexpr int IT16 = PL16 / 16 / 256, IT8 = PL8 / 16 / 256;                   // LDS-DMA pieces per thread: 4, 2 (+ 2)
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32, BK = 64, NT = WM * WN * 64;
+  static_assert((BM == 128 && NT == 256) || (BM == 256 && NT == 512), "128 rows per four waves");
+  constexpr int PL16 = BM * BK * 2, PL8 = BM * BK, STAGE = PL16 + 2 * PL8;     // 16 + 8 + 8 KB per 128 rows
+  constexpr int IT16 = PL16 / 16 / NT, IT8 = PL8 / 16 / NT;                     // LDS-DMA pieces per thread: 4, 2 (+ 2)
   constexpr int NDMA = IT16 + 2 * IT8;                                          // 8
   constexpr int NW16 = 4 * TN, NW8 = 4 * TN;                                    // W loads per lane per K-tile: fp16 (4 k-steps x TN), e4m3 (2 planes x TN x 2)
   constexpr unsigned kInvalid = 0xFFFFFFFFu;
@@ -525,7 +531,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f8_kernel(GemmArgs g) {
     nk = sg.K / BK;
 #pragma unroll
     for (int it = 0; it < IT16; ++it) {
-      const int p = it * 256 + tid, row = p >> 3, c = (p & 7) ^ ((row >> 1) & 7);
+      const int p = it * NT + tid, row = p >> 3, c = (p & 7) ^ ((row >> 1) & 7);
       int m = m0 + row; m = m < g.M ? m : g.M - 1;
       const int grp = m / sg.rows_out, r = m - grp * sg.rows_out;
       const int sr = r * sg.row_mul + sg.row_add;
@@ -533,7 +539,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f8_kernel(GemmArgs g) {
     }
 #pragma unroll
     for (int it = 0; it < IT8; ++it) {
-      const int p = it * 256 + tid, row = p >> 2, c = (p & 3) ^ ((row >> 2) & 3);
+      const int p = it * NT + tid, row = p >> 2, c = (p & 3) ^ ((row >> 2) & 3);
       int m = m0 + row; m = m < g.M ? m : g.M - 1;
       const int grp = m / sg.rows_out, r = m - grp * sg.rows_out;
       const int sr = r * sg.row_mul + sg.row_add;
@@ -566,13 +572,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f8_kernel(GemmArgs g) {
     constexpr int OP = decltype(op_t)::value;
     if constexpr (OP < IT16) {
       const unsigned o = a16o[OP];
-      glds16(o != kInvalid ? (const void*)(a16b + o) : (const void*)g.zeros, stage + (OP * 256 + wave * 64) * 16);
+      glds16(o != kInvalid ? (const void*)(a16b + o) : (const void*)g.zeros, stage + (OP * NT + wave * 64) * 16);
     } else if constexpr (OP < IT16 + IT8) {
       const unsigned o = a8o[OP - IT16];
-      glds16(o != kInvalid ? (const void*)(a8b + o) : (const void*)g.zeros, stage + PL16 + ((OP - IT16) * 256 + wave * 64) * 16);
+      glds16(o != kInvalid ? (const void*)(a8b + o) : (const void*)g.zeros, stage + PL16 + ((OP - IT16) * NT + wave * 64) * 16);
     } else {
       const unsigned o = a8o[OP - IT16 - IT8];
-      glds16(o != kInvalid ? (const void*)(al8b + o) : (const void*)g.zeros, stage + PL16 + PL8 + ((OP - IT16 - IT8) * 256 + wave * 64) * 16);
+      glds16(o != kInvalid ? (const void*)(al8b + o) : (const void*)g.zeros, stage + PL16 + PL8 + ((OP - IT16 - IT8) * NT + wave * 64) * 16);
     }
   };
 
@@ -739,10 +745,10 @@ int launch_f8(GemmArgs a, hipStream_t s) {
   a.group_n = 0; a.gm = g_gm;
   if (a.nseg == 1) {
     AWT_ONCE_PER_DEVICE(AWT_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_f8_kernel<EPI, CFG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)));
-    hipLaunchKernelGGL((gemm_f8_kernel<EPI, CFG, false>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((gemm_f8_kernel<EPI, CFG, false>), dim3(a.tiles_m * a.tiles_n), dim3(CFG::WM * CFG::WN * 64), lds, s, a);
   } else {
     AWT_ONCE_PER_DEVICE(AWT_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_f8_kernel<EPI, CFG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)));
-    hipLaunchKernelGGL((gemm_f8_kernel<EPI, CFG, true>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((gemm_f8_kernel<EPI, CFG, true>), dim3(a.tiles_m * a.tiles_n), dim3(CFG::WM * CFG::WN * 64), lds, s, a);
   }
   AWT_HIP_CHECK(hipGetLastError());
   return AWT_OK;
@@ -780,7 +786,8 @@ int launch_epi(GemmArgs a, int prec, hipStream_t s) {
       const int64_t t256f = (int64_t)((a.M + 127) / 128) * (a.N / 256);
       int tile = g_force_tile;
       if (!tile) tile = (a.N % 256 == 0 && t256f >= kSlots) ? 256 : 128;
-      if (tile == 256 && a.N % 256 == 0) return launch_f8<EPI, CfgF8W4>(a, s);
+      if (tile == 512 && a.N % 256 == 0 && a.nseg == 1) return launch_f8<EPI, CfgF8Big>(a, s);
+      if (tile >= 256 && a.N % 256 == 0) return launch_f8<EPI, CfgF8W4>(a, s);
       return launch_f8<EPI, CfgF8Sq>(a, s);
     }
   }
