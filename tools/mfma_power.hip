@@ -8,7 +8,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) int i32x8;
 
-template <int SHAPE>
+template <int SHAPE, int FMT = 0>
 __global__ __launch_bounds__(256, 2) void k(const bf16x8* in, float* out, int iters) {
   bf16x8 a[4], b[4];
   for (int i = 0; i < 4; ++i) { a[i] = in[threadIdx.x + 256 * i]; b[i] = in[threadIdx.x + 256 * (4 + i)]; }
@@ -35,8 +35,8 @@ __global__ __launch_bounds__(256, 2) void k(const bf16x8* in, float* out, int it
       for (int i = 0; i < 32; ++i) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[(i + r) & 3], b[(i >> 2) & 3], acc[i], 0, 0, 0);
-        acc[i] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(qa[i & 1], qb[(i >> 1) & 1], acc[i], 0, 0, 0, sa, 0, sb);
-        acc[i] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(qa[(i + 1) & 1], qb[(i >> 2) & 1], acc[i], 0, 0, 0, sa, 0, sb);
+        acc[i] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(qa[i & 1], qb[(i >> 1) & 1], acc[i], FMT, FMT, 0, sa, 0, sb);
+        acc[i] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(qa[(i + 1) & 1], qb[(i >> 2) & 1], acc[i], FMT, FMT, 0, sa, 0, sb);
       }
     }
     float s = 0;
@@ -76,7 +76,7 @@ int main(int argc, char** argv) {
   unsigned short* h = (unsigned short*)malloc(2048 * 16);
   srand(1);
   for (int i = 0; i < 2048 * 8; ++i) h[i] = (unsigned short)(0x3f00 + (rand() & 0xff) + ((rand() & 1) << 15));   // random mantissas, |x| in [0.5, 1)
-  if (shape == 8) for (int i = 1024 * 8; i < 2048 * 8; ++i) h[i] = (unsigned short)(rand() & 0x7777) | (unsigned short)(rand() & 0x8080);   // fp8 bytes, no NaN
+  if (shape == 8 || shape == 6 || shape == 4) for (int i = 1024 * 8; i < 2048 * 8; ++i) h[i] = (unsigned short)(rand() & 0x7777) | (unsigned short)(rand() & 0x8080);   // fp8 bytes, no NaN
   hipMemcpy(in, h, 2048 * 16, hipMemcpyHostToDevice);
   const int iters = 20000;   // x 32 MFMAs (16x16x32) or 16 (32x32x16): same flops per iteration
   auto t0 = std::chrono::steady_clock::now(); long n = 0;
@@ -84,6 +84,8 @@ int main(int argc, char** argv) {
     for (int r = 0; r < 10; ++r) {
       if (shape == 16) hipLaunchKernelGGL(k<16>, dim3(512), dim3(256), 0, 0, in, out, iters);
       else if (shape == 8) hipLaunchKernelGGL(k<8>, dim3(512), dim3(256), 0, 0, in, out, iters);
+      else if (shape == 6) hipLaunchKernelGGL((k<8, 3>), dim3(512), dim3(256), 0, 0, in, out, iters);   // cross terms in bf6 (e3m2)
+      else if (shape == 4) hipLaunchKernelGGL((k<8, 4>), dim3(512), dim3(256), 0, 0, in, out, iters);   // cross terms in fp4 (e2m1)
       else if (shape == 3) hipLaunchKernelGGL(k<3>, dim3(512), dim3(256), 0, 0, in, out, iters);
       else hipLaunchKernelGGL(k<32>, dim3(512), dim3(256), 0, 0, in, out, iters);
     }
@@ -91,7 +93,7 @@ int main(int argc, char** argv) {
   }
   const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   const double flops = (double)n * 512 * 4 * iters * 32 * 16384.0;
-  if (shape == 8 || shape == 3) printf("shape %d: %.3f us per (32 tiles x K=128) round\n", shape, dt / ((double)n * (iters / 4)) * 1e6);
+  if (shape == 8 || shape == 3 || shape == 6 || shape == 4) printf("shape %d: %.3f us per (32 tiles x K=128) round\n", shape, dt / ((double)n * (iters / 4)) * 1e6);
   else printf("shape %d: %.1f TFLOP/s\n", shape, flops / dt / 1e12);
   return 0;
 }
