@@ -116,7 +116,11 @@ class NativeWhisperEncoder(nn.Module):
                  device: str = "cuda", chunk_clips: int = 0, seed: Optional[int] = 0, init_profile: str = "hf",
                  trainable: bool = False, backward_precision: Optional[str] = None):
         super().__init__()
-        if precision is None:       # default: the fastest mode that meets the 1e-3 bound; training keeps bf16 planes
+        # precision=None: training keeps bf16 planes; inference takes the fastest mode that meets the 1e-3 bound for the weights at hand --
+        # f16f8, unless the checkpoint has outlier channels (choose_precision), where the 15-bit scheme's relative error turns into
+        # absolute errors above the bound and the split-fp16 mode is used instead.  Re-decided when base weights change.
+        self._auto_precision = precision is None and not trainable
+        if precision is None:
             precision = "bf16x3" if trainable else DEFAULT_PRECISION
         if backward_precision not in (None, precision, "bf16"):
             raise ValueError("backward_precision must be None (= precision) or 'bf16'")
@@ -171,9 +175,38 @@ class NativeWhisperEncoder(nn.Module):
     def get_input_embeddings(self):
         return self.conv1
 
+    # outlier thresholds of the automatic mode: largest LayerNorm gain over the median gain, largest out_proj / fc2 row norm over the median
+    AUTO_GAIN_RATIO, AUTO_ROW_RATIO = 8.0, 5.0
+
+    def choose_precision(self) -> str:
+        """'f16f8' or 'fp16x3' from the weights alone: LayerNorm gains and out_proj / fc2 rows far above their medians are what turns a
+        relative operand error into a large absolute one (tests/test_gpu_encoder.py outlier profile: f16f8 8e-2, fp16x3 7e-4 at outputs of
+        66).  One device reduction per tensor, one host sync in total; `self.precision_report` keeps the two ratios."""
+        stats = []
+        for name, p in self.named_parameters():
+            if name.endswith("layer_norm.weight"):
+                a = p.detach().abs().float()
+                stats.append(torch.stack([a.max() / a.median().clamp_min(1e-12), a.new_zeros(())]))
+            elif name.endswith(("out_proj.weight", "fc2.weight")):
+                n = p.detach().float().norm(dim=1)
+                stats.append(torch.stack([n.new_zeros(()), n.max() / n.median().clamp_min(1e-12)]))
+        gain, row = (float(v) for v in torch.stack(stats).amax(dim=0).tolist())
+        choice = "fp16x3" if (gain > self.AUTO_GAIN_RATIO or row > self.AUTO_ROW_RATIO) else DEFAULT_PRECISION
+        self.precision_report = {"layernorm_gain_ratio": gain, "row_norm_ratio": row, "precision": choice}
+        return choice
+
+    def _drop_handle(self):
+        if self._handle is not None:
+            _lib.lib().awt_encoder_destroy(self._handle)
+            self._handle = None
+        self._synced.clear()
+        self._ws = None
+
     def _ensure_handle(self):
         if self._handle is not None:
             return
+        if self._auto_precision:
+            self.precision = self.choose_precision()
         L = _lib.lib()
         bits = 0
         if self.lora is not None:
@@ -197,6 +230,10 @@ class NativeWhisperEncoder(nn.Module):
             self._param_cache = list(self.named_parameters())
         if not force and all(self._synced.get(name) == p._version for name, p in self._param_cache):
             return 0
+        if self._auto_precision and self._synced and any(self._synced.get(name) != p._version and "lora_" not in name for name, p in self._param_cache):
+            if self.choose_precision() != self.precision:      # new base weights (load_state_dict after a forward) call for the other mode
+                self._drop_handle()
+                self._ensure_handle()
         with torch.cuda.device(self.device):
             for name, p in self._param_cache:
                 ver = p._version

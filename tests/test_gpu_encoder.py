@@ -252,3 +252,29 @@ def test_outlier_channels_keep_the_relative_error(precision):
     print(precision, e)
     assert float(np.abs(ref).max()) > 30.0
     assert e["rel_l2"] < OUTLIER_TOL[precision][0] and e["max_abs"] < OUTLIER_TOL[precision][1], e
+
+
+def test_default_precision_follows_the_checkpoint():
+    """precision=None: f16f8 for ordinary weights, split-fp16 when LayerNorm gains / out_proj / fc2 rows have outliers -- decided at the
+    first forward and re-decided when new base weights are loaded; the outlier profile then stays at fp32-level error."""
+    from mlx8_ws_audio_transformer_amd.encoder import NativeWhisperEncoder
+    cfg = wts.config("tiny", True)
+    plain = wts.init_encoder_weights(cfg, 0, "test")
+    W = wts.with_outlier_channels(plain, cfg, seed=0)
+    mel = _mel(cfg, 2)
+    enc = NativeWhisperEncoder(cfg, seed=0, init_profile="test").eval()            # precision=None
+    enc(torch.from_numpy(mel).cuda())
+    assert enc.precision == "f16f8" and enc.precision_report["layernorm_gain_ratio"] < 2
+    enc.load_state_dict({k: torch.from_numpy(v) for k, v in W.items()})
+    out = enc(torch.from_numpy(mel).cuda()).last_hidden_state.cpu().numpy()
+    assert enc.precision == "fp16x3" and enc.precision_report["layernorm_gain_ratio"] > 8
+    ref = oracle_enc.encoder_forward(W, mel, cfg.heads, dtype=torch.float64).numpy()
+    e = oracle_enc.error_norms(out, ref)
+    assert e["rel_l2"] < OUTLIER_TOL["fp16x3"][0] and e["max_abs"] < OUTLIER_TOL["fp16x3"][1], e
+    enc.load_state_dict({k: torch.from_numpy(v) for k, v in plain.items()})
+    enc(torch.from_numpy(mel).cuda())
+    assert enc.precision == "f16f8"
+    explicit = NativeWhisperEncoder(cfg, precision="f16f8", seed=0, init_profile="test").eval()   # an explicit choice is never overridden
+    explicit.load_state_dict({k: torch.from_numpy(v) for k, v in W.items()})
+    explicit(torch.from_numpy(mel).cuda())
+    assert explicit.precision == "f16f8"

@@ -100,3 +100,17 @@ def test_note_tokenizer_roundtrip_and_collator_padding():
     batch = coll(feats)
     assert batch["labels"].shape == (2, len(both[0]) - 1)    # every row starts with BOS: the collator strips it (fineTune.py:114-115)
     assert (batch["labels"][1, len(both[1]) - 1:] == -100).all()
+
+
+def test_automatic_precision_choice_reads_the_weights_only():
+    """NativeWhisperEncoder(precision=None).choose_precision(): pure function of the parameters (runs on CPU tensors too)."""
+    from mlx8_ws_audio_transformer_amd import weights as wts
+    from mlx8_ws_audio_transformer_amd.encoder import NativeWhisperEncoder
+    cfg = wts.config("mini", True)
+    enc = NativeWhisperEncoder(cfg, device="cpu", seed=0, init_profile="hf")
+    assert enc.choose_precision() == "f16f8" and enc.precision_report["row_norm_ratio"] < 5
+    W = wts.with_outlier_channels(wts.init_encoder_weights(cfg, 0, "test"), cfg, seed=0)
+    enc.load_state_dict({k: torch.from_numpy(v) for k, v in W.items()})
+    assert enc.choose_precision() == "fp16x3"
+    rep = enc.precision_report
+    assert rep["layernorm_gain_ratio"] > 8 and rep["precision"] == "fp16x3"
