@@ -223,6 +223,7 @@ class NativeWhisperEncoder(nn.Module):
 
     def sync_weights(self, force: bool = False) -> int:
         """Push every parameter that changed since the last push (tracked by tensor version) to the library."""
+        fresh = self._handle is None       # the mode has just been decided from the current weights
         self._ensure_handle()
         L = _lib.lib()
         n = 0
@@ -230,7 +231,7 @@ class NativeWhisperEncoder(nn.Module):
             self._param_cache = list(self.named_parameters())
         if not force and all(self._synced.get(name) == p._version for name, p in self._param_cache):
             return 0
-        if self._auto_precision and self._synced and any(self._synced.get(name) != p._version and "lora_" not in name for name, p in self._param_cache):
+        if self._auto_precision and not fresh and any(self._synced.get(name) != p._version and "lora_" not in name for name, p in self._param_cache):
             if self.choose_precision() != self.precision:      # new base weights (load_state_dict after a forward) call for the other mode
                 self._drop_handle()
                 self._ensure_handle()
