@@ -5,7 +5,7 @@ import torch
 from mlx8_ws_audio_transformer_amd import weights as wts, synth
 from mlx8_ws_audio_transformer_amd.encoder import NativeWhisperEncoder
 cfg = wts.config("small")
-enc = NativeWhisperEncoder(cfg, precision="bf16x3").eval()
+enc = NativeWhisperEncoder(cfg, precision=sys.argv[1] if len(sys.argv) > 1 else None).eval()   # default: the mode chosen from the weights (f16f8)
 pcm = torch.from_numpy(synth.synth_clips_i16(64, seed=1234)).cuda()
 ref = enc.encode_pcm(pcm).clone()
 t0 = time.time(); bad = 0
