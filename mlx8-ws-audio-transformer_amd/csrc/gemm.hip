@@ -707,6 +707,17 @@ __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, CFG::WM * CFG::WN == 4 ? 2 
   // layout: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)); a lane then owns EIGHT consecutive columns of a row
   // (8 lanes per row, 8 rows per pass): 32-byte fp32 / 16-byte fp16 / 8-byte e4m3 stores, whole 256-byte row segments per plane.
   static_assert(TN == 2, "epilogue strips are 64 columns wide");
+#ifdef AWT_DIAG_NO_EPI      // timing-only build: the accumulators are consumed by one store per lane instead of the epilogue
+  { float sacc = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) sacc += acc[i][j][rr];
+    if (sacc == 123.456f) g.out.f32[0] = sacc;
+    return; }
+#endif
   constexpr int PITCH = 72;   // floats: 288-byte rows keep the two 16-byte reads of a lane 16-byte aligned
   float* patch = reinterpret_cast<float*>(smem) + wave * (32 * PITCH);      // 9216 B per wave
   const int c8 = (lane & 7) * 8, r8 = lane >> 3;
