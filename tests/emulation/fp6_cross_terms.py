@@ -1,3 +1,5 @@
+"""CPU estimate (fp64 + operand rounding) of the hidden-state error of ONE design change with everything else exact.  Not a test and not
+product code: it imports oracle/ (allowed under tests/ only).  Run from the repository root: python tests/emulation/<this file> [tiny|small]."""
 import sys, time
 sys.path.insert(0, '/root/repo')
 import numpy as np, torch
