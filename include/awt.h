@@ -113,7 +113,8 @@ typedef struct awt_encoder_cfg {
                                3 bf16x3: split-bf16 hi + lo planes, three MFMAs (2^-17 per operand; the training format);
                                4 fp16x3: split-fp16 planes, three MFMAs (2^-23 per operand; operands within fp16's range);
                                5 f16f8: fp16 plane + two e4m3 planes, the two cross terms on the block-scaled fp8 MFMA: two
-                                 MFMA-equivalents per fragment pair (2^-16 per operand); inference only                  */
+                                 MFMA-equivalents per fragment pair (2^-16 per operand); inference only.  Its attention keeps
+                                 the cross terms of q k^T and runs P V as one fp16 product           */
   int32_t lora_rank;        /* 0 = no adapters; else 1..64                                                 */
   float lora_alpha;         /* adapter scale = lora_alpha / lora_rank                                      */
   uint32_t lora_targets;    /* bit mask of AWT_LORA_*                                                      */
@@ -268,9 +269,13 @@ int awt_op_attention_small_backward(awt_ctx* c, const float* q, int ldq, const f
                                     const float* dout, int ldo, const float* lse, float* delta, float* dq, float* dk, float* dv, int B,
                                     int H, int Lq, int Sk, int causal, int causal_off, void* stream);
 
-/* Process-wide tuning / test hooks (no effect on results).  key "gemm_tile": 0 = choose the GEMM block tile from the
- * shape (default), 64 / 128 / 256 = force the 64 x 128, 128 x 128 or 128 x 256 tile (256 falls back to 128 when N is not
- * a multiple of 256) so that tests can drive every tiling on small shapes. */
+/* Process-wide tuning / test hooks.  key "gemm_tile": 0 = choose the GEMM block tile from the shape (default), 64 / 128 / 256 =
+ * force the 64 x 128, 128 x 128 or 128 x 256 tile (256 falls back to 128 when N is not a multiple of 256) so that tests can
+ * drive every tiling on small shapes; 512 = the 256 x 256 eight-wave tile of the f16f8 GEMM (same results, slower).
+ * "gemm_gm": row panels per tile-order group (0 = default).  "attn_shape": workgroup shape of the f16f8 attention kernel, 0 =
+ * automatic; 1..5 keep the e4m3 cross terms of P V (plain 4x32 / 4x64 / 6x32 queries, software-pipelined 4 / 8 waves), 6 / 7 =
+ * software-pipelined 4 / 8 waves with P V as one fp16 product (what 0 selects for inference).  Only the last choice changes
+ * results (within the tolerances of DESIGN.md section 3); every other value is bit-neutral. */
 int awt_tuning_set(const char* key, int value);
 
 /* ------------------------------------------------------------------------------------------------------

@@ -471,6 +471,10 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f16f8_pipe_kernel(Attn8A
       }(), ...);
     }(std::make_integer_sequence<int, 12>{});
   }
+  // iteration 0 stages the next K tile into the slot K(0) was just read from: every wave has to be past its S(0) reads first
+  // (the LDS-DMA lands microseconds later, so the race was never observed -- it is closed all the same)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();
 
   // one iteration: softmax + PV of tile kt (scores in sc), and -- unless LAST -- the scores of tile kt + 1 into sn
   auto iter = [&](auto last_t, auto tail_t, int kt, f32x16 (&sc)[2], f32x16 (&sn)[2]) {
