@@ -693,6 +693,17 @@ extern "C" int awt_op_linear(awt_ctx* c, const float* x, const float* w, const f
   bf16_t* xl = (bf16_t*)base;                 base += align_up((size_t)M * K * 2);
   bf16_t* wh = (bf16_t*)base;                 base += align_up((size_t)N * K * 2);
   bf16_t* wl = (bf16_t*)base;
+  if (terms == PREC_F16F6) {   // experimental: fp16 plane + two e3m2 planes (the second 2-byte plane's space holds both, 0.75 B per element each)
+    AWT_REQUIRE(N % 256 == 0, AWT_ERR_INVALID, "op_linear (f16f6): N % 256 == 0 required");
+    Act ax6; ax6.p16 = xh; ax6.hi8 = (uint8_t*)xl; ax6.lo8 = (uint8_t*)xl + (size_t)M * K / 4 * 3;
+    uint8_t* w6 = (uint8_t*)wl; uint8_t* wl6 = w6 + (size_t)N * K / 4 * 3;
+    int rc6 = launch_split_planes_f6(c, x, M, K, xh, ax6.hi8, ax6.lo8, s); if (rc6) return rc6;
+    rc6 = launch_pack_weight_f6(c, w, N, K, wh, w6, wl6, s); if (rc6) return rc6;
+    Planes pw6; pw6.hi = wh; pw6.lo = (bf16_t*)w6; pw6.x8 = wl6; pw6.rows = N; pw6.ld = K;
+    GemmSeg sg6 = seg_plain(ax6, K, pw6, 0, K, M);
+    GemmOut o6{}; o6.f32 = y; o6.ldo = N; o6.bias = bias; o6.n_valid = N;
+    return launch_gemm(c, M, N, &sg6, 1, terms, EPI_F32, o6, s);
+  }
   const Act ax = make_act(xh, xl, (size_t)M * K, terms);
   int rc = launch_split_planes(c, x, (int64_t)M * K, 1.0f, terms, kF8Act, xh, xl, ax.hi8, ax.lo8, s); if (rc) return rc;
   rc = launch_pack_weight(c, w, N, K, 1, K, 0, 0, 1.0f, wh, wl, (uint8_t*)wl + (size_t)N * K, terms, s); if (rc) return rc;     // fragment-major

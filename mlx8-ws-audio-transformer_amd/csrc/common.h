@@ -27,8 +27,8 @@ typedef int i32x2 __attribute__((ext_vector_type(2)));
 //                block-scaled fp8 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4, twice the fp16 rate): two MFMA-equivalents per
 //                fragment pair instead of three.  hi8 = e4m3(x 2^s), lo8 = e4m3((x - fp16(x)) 2^(s + 11)) with a FIXED
 //                power-of-two s per operand role (below), so no reduction pass is needed to write a plane.
-enum { PREC_BF16 = 1, PREC_BF16X3 = 3, PREC_F16X3 = 4, PREC_F16F8 = 5 };
-__host__ __device__ constexpr bool prec_is_f16(int p) { return p == PREC_F16X3 || p == PREC_F16F8; }
+enum { PREC_BF16 = 1, PREC_BF16X3 = 3, PREC_F16X3 = 4, PREC_F16F8 = 5, PREC_F16F6 = 6 };
+__host__ __device__ constexpr bool prec_is_f16(int p) { return p == PREC_F16X3 || p == PREC_F16F8 || p == PREC_F16F6; }
 __host__ __device__ constexpr int prec_products(int p) { return p == PREC_BF16 ? 1 : 3; }   // split products formed (cross terms may be fp8)
 // fixed exponents of the e4m3 planes: |x| 2^s must stay <= 448 (saturates beyond); values below 2^(-6 - s) are subnormal
 // (absolute error 2^(-10 - s)), which is far below the cross terms' weight in any dot product they enter
@@ -79,6 +79,30 @@ __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
   if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
   else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
+// ---- PREC_F16F6 (experimental, single-operator path only): like PREC_F16F8 with the two correction planes in FP6 e3m2 ("bf6", the block-scaled
+// MFMA runs it at twice e4m3's rate): 32 consecutive k of a row are 24 bytes, packed by v_cvt_scalef32_2xpk16_bf6_f32 from k 0..15 and k 16..31
+// of the group (probed, tools/f6_probe.hip: result = fp6(x / scale), round to nearest, saturates at +-28, element 2 m = a[m], 2 m + 1 = b[m]).
+// The order inside a group is immaterial as long as both operands are packed the same way.  Fixed exponents: activations x 2^1, weights x 2^7.
+constexpr int kF6Act = 1, kF6Wgt = 7;
+typedef float f32x16v __attribute__((ext_vector_type(16)));
+typedef unsigned u32x6 __attribute__((ext_vector_type(6)));
+template <int S>
+__device__ __forceinline__ u32x6 bf6x32(const float (&v)[32]) {
+  f32x16v a, b;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { a[i] = v[i]; b[i] = v[16 + i]; }
+  return __builtin_amdgcn_cvt_scalef32_2xpk16_bf6_f32(a, b, S >= 0 ? 1.0f / (float)(1ull << (S >= 0 ? S : 0)) : (float)(1ull << (S < 0 ? -S : 0)));
+}
+template <int SA, int SB>
+__device__ __forceinline__ f32x16 mfma32_f6(i32x8 a, i32x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 3, 3, 0, SA, 0, SB);
+}
+// weight images of PREC_F16F6: fp16 plane in w16f8_index order; each e3m2 plane fragment-major, 24 bytes per lane (row n & 31, half (k & 63) >> 5)
+__host__ __device__ __forceinline__ int64_t w6_byte_index(int n, int k, int ktiles64) {
+  const int nt = n >> 5, r = n & 31, kt = k >> 6, h = (k & 63) >> 5;
+  return (((int64_t)nt * ktiles64 + kt) * 64 + (h * 32 + r)) * 24;
+}
+
 // block-scaled e4m3 x e4m3 product with one power-of-two scale per operand (E8M0 bytes SA, SB)
 template <int SA, int SB>
 __device__ __forceinline__ f32x16 mfma32_f8(i32x8 a, i32x8 b, f32x16 c) {
@@ -279,6 +303,9 @@ int launch_attention_f16f8(awt_ctx* c, const F8Planes& q, const F8Planes& k, con
 // fragment-major matrix with ld / 32 k-steps (ld = its K, a multiple of 32; its row count a multiple of 16)
 // prec PREC_F16F8: hi = fp16 plane (w16f8_index order), lo = the hi8 plane, lo8 = the lo8 plane (w8_index order); else hi / lo in
 // w_frag_index order (bf16, or fp16 for PREC_F16X3) and lo8 unused
+// PREC_F16F6 (single-operator path): x [M, K] -> fp16 plane + two e3m2 planes (row pitch K * 3 / 4 bytes); w [N, K] -> fragment-major images
+int launch_split_planes_f6(awt_ctx* c, const float* x, int M, int K, bf16_t* p16, uint8_t* hi6, uint8_t* lo6, hipStream_t s);
+int launch_pack_weight_f6(awt_ctx* c, const float* w, int N, int K, bf16_t* w16, uint8_t* hi6, uint8_t* lo6, hipStream_t s);
 int launch_pack_weight(awt_ctx* c, const float* src, int N, int C, int taps, int64_t ld, int row_off, int col_off, float scale,
                        bf16_t* hi, bf16_t* lo, uint8_t* lo8, int prec, hipStream_t s);
 // conv1 im2col: mel f32 [B, C, T] -> A [B*T, K_dst] bf16 hi/lo, k = dt * C + c reads mel[b, c, t + dt - 1]

@@ -335,6 +335,46 @@ __global__ __launch_bounds__(256) void outer_reduce_final_kernel(const float* __
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------ PREC_F16F6 operand images (experimental)
+// One thread per (row, group of 32 consecutive k): fp16 plane + the two e3m2 planes.  WEIGHT: fragment-major images, exponent kF6Wgt.
+template <bool WEIGHT>
+__global__ __launch_bounds__(256) void planes_f6_kernel(const float* __restrict__ x, int M, int K, bf16_t* p16, uint8_t* hi6, uint8_t* lo6) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int groups = K >> 5;
+  if (idx >= (int64_t)M * groups) return;
+  const int m = (int)(idx / groups), g = (int)(idx - (int64_t)m * groups);
+  const float* src = x + (int64_t)m * K + 32 * g;
+  float v[32], lo[32];
+  bf16_t h[32];
+#pragma unroll
+  for (int i = 0; i < 32; i += 4) { const float4 t = *reinterpret_cast<const float4*>(src + i); v[i] = t.x; v[i + 1] = t.y; v[i + 2] = t.z; v[i + 3] = t.w; }
+#pragma unroll
+  for (int i = 0; i < 32; ++i) { h[i] = f32_to_f16(v[i]); lo[i] = v[i] - f16_to_f32(h[i]); }
+  constexpr int S = WEIGHT ? kF6Wgt : kF6Act;
+  const u32x6 qh = bf6x32<S>(v), ql = bf6x32<S + kF8Lo>(lo);
+  uint8_t *dh, *dl;
+  if (WEIGHT) {
+    const int64_t o = w6_byte_index(m, 32 * g, K >> 6);
+    dh = hi6 + o; dl = lo6 + o;
+#pragma unroll
+    for (int c8 = 0; c8 < 4; ++c8)
+      *reinterpret_cast<uint4*>(p16 + w16f8_index(m, 32 * g + 8 * c8, K >> 4)) =
+          make_uint4(pack2(h[8 * c8], h[8 * c8 + 1]), pack2(h[8 * c8 + 2], h[8 * c8 + 3]), pack2(h[8 * c8 + 4], h[8 * c8 + 5]), pack2(h[8 * c8 + 6], h[8 * c8 + 7]));
+  } else {
+    const int64_t o = (int64_t)m * (K / 4 * 3) + 24 * g;
+    dh = hi6 + o; dl = lo6 + o;
+#pragma unroll
+    for (int c8 = 0; c8 < 4; ++c8)
+      *reinterpret_cast<uint4*>(p16 + (int64_t)m * K + 32 * g + 8 * c8) =
+          make_uint4(pack2(h[8 * c8], h[8 * c8 + 1]), pack2(h[8 * c8 + 2], h[8 * c8 + 3]), pack2(h[8 * c8 + 4], h[8 * c8 + 5]), pack2(h[8 * c8 + 6], h[8 * c8 + 7]));
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    *reinterpret_cast<uint2*>(dh + 8 * i) = make_uint2(qh[2 * i], qh[2 * i + 1]);
+    *reinterpret_cast<uint2*>(dl + 8 * i) = make_uint2(ql[2 * i], ql[2 * i + 1]);
+  }
+}
 }  // namespace
 
 int launch_layernorm(awt_ctx* c, const float* x, const float* gamma, const float* beta, int M, int d, float eps,
@@ -460,5 +500,20 @@ int launch_outer_reduce(awt_ctx* c, const bf16_t* x_hi, const bf16_t* x_lo, int6
                                    partial, partial_bytes, accumulate, s);
     if (rc) return rc;
   }
+  return AWT_OK;
+}
+
+int launch_split_planes_f6(awt_ctx* c, const float* x, int M, int K, bf16_t* p16, uint8_t* hi6, uint8_t* lo6, hipStream_t s) {
+  AWT_REQUIRE(x && p16 && hi6 && lo6 && M > 0 && K > 0 && K % 64 == 0, AWT_ERR_INVALID, "split_planes_f6: K must be a multiple of 64");
+  const int64_t n = (int64_t)M * (K / 32);
+  hipLaunchKernelGGL(planes_f6_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, M, K, p16, hi6, lo6);
+  AWT_HIP_CHECK(hipGetLastError());
+  return AWT_OK;
+}
+int launch_pack_weight_f6(awt_ctx* c, const float* w, int N, int K, bf16_t* w16, uint8_t* hi6, uint8_t* lo6, hipStream_t s) {
+  AWT_REQUIRE(w && w16 && hi6 && lo6 && N > 0 && N % 32 == 0 && K > 0 && K % 64 == 0, AWT_ERR_INVALID, "pack_weight_f6: N % 32 == 0 and K % 64 == 0 required");
+  const int64_t n = (int64_t)N * (K / 32);
+  hipLaunchKernelGGL(planes_f6_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, N, K, w16, hi6, lo6);
+  AWT_HIP_CHECK(hipGetLastError());
   return AWT_OK;
 }

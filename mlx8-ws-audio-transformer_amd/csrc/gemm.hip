@@ -765,6 +765,248 @@ int launch_f8(GemmArgs a, hipStream_t s) {
   return AWT_OK;
 }
 
+
+// ================================================================================================ PREC_F16F6 (experimental)
+// The f16f8 kernel with the two correction planes in FP6 e3m2: per fragment pair the fp16 product (4 x 32 pipe cycles per 64-deep K-tile and
+// 32 x 32 tile) plus two block-scaled FP6 products of 32 cycles each = 1.5 bf16-MFMA-equivalents instead of 2, and 3.5 instead of 4 operand
+// bytes per element.  128 x 256 on four waves, single K segment, fp32 output (the single-operator path `awt_op_linear`, precision 6); the encoder
+// does not use it yet: its producers (LayerNorm, GELU epilogue, attention output) would have to emit 32-consecutive-k groups.
+// LDS stage: A16 (16 KB) | A_hi6 (6 KB: 128 rows x 48 B) | A_lo6 (6 KB).  A lane (row r, half h) reads its 24 bytes as three ds_read_b64.
+template <int OFF>
+__device__ __forceinline__ i32x2 lds_read8a(unsigned addr) {
+  i32x2 v;
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+template <int OFF>
+__device__ __forceinline__ i32x2 gload8(unsigned voff, const void* sbase) {
+  i32x2 v;
+  asm volatile("global_load_dwordx2 %0, %1, %2 offset:%3" : "=v"(v) : "v"(voff), "s"(sbase), "n"(OFF));
+  return v;
+}
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_f6_kernel(GemmArgs g) {
+  constexpr int TM = 4, TN = 2, BM = 128, BN = 256, BK = 64, NT = 256;
+  constexpr int PL16 = BM * BK * 2, PL6 = BM * 48, STAGE = PL16 + 2 * PL6;     // 16 + 6 + 6 KB
+  constexpr int IT16 = PL16 / 16 / NT, IT6 = 2 * PL6 / 16 / NT;                 // 4 + 3 LDS-DMA pieces per thread
+  constexpr int NDMA = IT16 + IT6;
+  constexpr int NW16 = 4 * TN, NW6 = 2 * TN * 2;                                // W loads per lane per K-tile: fp16, e3m2 (2 planes x TN x (16 B + 8 B))
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tid = wave * 64 + lane;
+  const int nwg = g.tiles_m * g.tiles_n;
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int qn = nwg >> 3, rn = nwg & 7;
+  const int tile = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + idx;
+  const int GM = g.gm;
+  int tm, tn;
+  {
+    const int grp = tile / (GM * g.tiles_n);
+    const int gm = min(GM, g.tiles_m - grp * GM);
+    const int within = tile - grp * GM * g.tiles_n;
+    tn = within / gm; tm = grp * GM + (within - tn * gm);
+  }
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int wc = wave;                       // 1 x 4 waves: wave w owns columns 64 w .. 64 w + 63 of the tile
+  const int r32 = lane & 31, half = lane >> 5;
+  const GemmSeg& sg = g.seg[0];
+  const int ktiles = sg.K / BK;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x16){};
+
+  // ---- A streams: per-thread byte offsets of the DMA pieces (fixed), bases advanced per K-tile
+  unsigned a16o[IT16], a6o[IT6];
+#pragma unroll
+  for (int it = 0; it < IT16; ++it) {
+    const int p = it * NT + tid, row = p >> 3, c = (p & 7) ^ ((row >> 1) & 7);
+    int m = m0 + row; m = m < g.M ? m : g.M - 1;
+    a16o[it] = (unsigned)(((int64_t)m * sg.lda + c * 8) * 2);
+  }
+  const int64_t pitch6 = sg.lda / 4 * 3;                          // bytes per row of an e3m2 plane
+  const int64_t plane6 = (const char*)sg.al8 - (const char*)sg.a8;   // the lo6 plane follows the hi6 plane (checked on the host: < 4 GB)
+#pragma unroll
+  for (int it = 0; it < IT6; ++it) {
+    const int q = it * NT + tid, pl = q >= 384, within = q - pl * 384, row = within / 3, c = within - row * 3;
+    int m = m0 + row; m = m < g.M ? m : g.M - 1;
+    a6o[it] = (unsigned)(pl * plane6 + (int64_t)m * pitch6 + c * 16);
+  }
+  const char* a16b = (const char*)sg.a_hi;
+  const char* a6b = (const char*)sg.a8;
+  const int nt0 = (n0 >> 5) + wc * TN;
+  const int64_t w16_ts = (int64_t)sg.w_ksteps * 2 * 1024;           // bytes per 32-row n-tile of the fp16 plane
+  const int64_t w6_ts = (int64_t)(sg.w_ksteps / 2) * 1536;           // bytes per n-tile of an e3m2 plane: (K / 64) blocks of 64 x 24 B
+  const char *w16b[TN], *w6b[TN], *wl6b[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    w16b[j] = (const char*)sg.w_hi + (nt0 + j) * w16_ts;
+    w6b[j] = (const char*)sg.w8 + (nt0 + j) * w6_ts;
+    wl6b[j] = (const char*)sg.wl8 + (nt0 + j) * w6_ts;
+  }
+  const unsigned wl16 = lane * 16, wl24 = lane * 24;
+  int kk = 0;
+  auto advance = [&]() {
+    if (kk + 1 < ktiles) {
+      ++kk;
+      a16b += BK * 2; a6b += 48;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) { w16b[j] += 4 * 1024; w6b[j] += 1536; wl6b[j] += 1536; }
+    }
+  };
+  auto dma = [&](auto op_t, char* stage) {
+    constexpr int OP = decltype(op_t)::value;
+    if constexpr (OP < IT16) glds16(a16b + a16o[OP], stage + (OP * NT + wave * 64) * 16);
+    else glds16(a6b + a6o[OP - IT16], stage + PL16 + ((OP - IT16) * NT + wave * 64) * 16);
+  };
+  bf16x8 w16[4][TN];
+  bf16x8 w6a[TN], wl6a[TN];          // first 16 bytes of the lane's 24
+  i32x2 w6c[TN], wl6c[TN];           // last 8
+  auto load_w16 = [&](auto ks_t) {
+    constexpr int ks = decltype(ks_t)::value;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) w16[ks][j] = gload16<ks * 1024>(wl16, w16b[j]);
+  };
+  auto load_w6 = [&]() {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      w6a[j] = gload16<0>(wl24, w6b[j]); w6c[j] = gload8<16>(wl24, w6b[j]);
+      wl6a[j] = gload16<0>(wl24, wl6b[j]); wl6c[j] = gload8<16>(wl24, wl6b[j]);
+    }
+  };
+  auto cat6 = [](bf16x8 lo, i32x2 hi) -> i32x8 {
+    const i32x4_t l = __builtin_bit_cast(i32x4_t, lo);
+    return (i32x8){l[0], l[1], l[2], l[3], hi[0], hi[1], 0, 0};
+  };
+
+  [&]<int... O>(std::integer_sequence<int, O...>) { (dma(std::integral_constant<int, O>{}, smem), ...); }(std::make_integer_sequence<int, NDMA>{});
+  [&]<int... S>(std::integer_sequence<int, S...>) { (load_w16(std::integral_constant<int, S>{}), ...); }(std::make_integer_sequence<int, 4>{});
+  load_w6();
+  wait_vm<0>();
+  __builtin_amdgcn_s_barrier();
+
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)(smem);
+  unsigned a16a[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) a16a[ks] = lds0 + r32 * 128 + (((2 * ks + half) ^ ((r32 >> 1) & 7)) << 4);
+  unsigned a6a = lds0 + PL16 + r32 * 48 + 24 * half;
+
+  constexpr int DMA_PER_STEP = (NDMA + TM - 1) / TM;
+  auto ktile = [&](auto pf_t, int kt) {
+    constexpr bool PF = decltype(pf_t)::value;
+    char* nxt = smem + ((kt + 1) & 1) * STAGE;
+    if constexpr (PF) advance();
+    constexpr int AD = 3;
+    bf16x8 af[AD + 1];
+    auto read_a16 = [&](auto s_t) {
+      constexpr int S2 = decltype(s_t)::value;
+      af[S2 % (AD + 1)] = lds_read16<(S2 % TM) * 32 * 128>(a16a[S2 / TM]);
+    };
+    [&]<int... S>(std::integer_sequence<int, S...>) { (read_a16(std::integral_constant<int, S>{}), ...); }(std::make_integer_sequence<int, AD>{});
+    [&]<int... S>(std::integer_sequence<int, S...>) {
+      ([&] {
+        constexpr int ks = S / TM, i = S % TM;
+        if constexpr (S + AD < 4 * TM) read_a16(std::integral_constant<int, S + AD>{});
+        if constexpr (PF && ks == 0) {
+          [&]<int... O>(std::integer_sequence<int, O...>) {
+            ([&] { constexpr int op = i * DMA_PER_STEP + O; if constexpr (op < NDMA) dma(std::integral_constant<int, op>{}, nxt); }(), ...);
+          }(std::make_integer_sequence<int, DMA_PER_STEP>{});
+        }
+        constexpr int AHEAD = (4 * TM - 1 - S < AD ? 4 * TM - 1 - S : AD);
+        lgkm_wait<AHEAD>(af[S % (AD + 1)]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = mfma32<true>(af[S % (AD + 1)], w16[ks][j], acc[i][j]);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (PF && i == TM - 1) load_w16(std::integral_constant<int, ks>{});
+      }(), ...);
+    }(std::make_integer_sequence<int, 4 * TM>{});
+    // ---- e3m2 part: the six 8-byte reads of row tile i + 1 are issued before the four MFMAs of row tile i (two register sets), waits hand-counted
+    if constexpr (PF) wait_vm<NDMA + NW16>(); else wait_vm<0>();
+    i32x2 xy[2][6];
+    auto read_xy = [&](auto i_t, i32x2 (&d)[6]) {
+      constexpr int O = decltype(i_t)::value * 32 * 48;
+      d[0] = lds_read8a<O>(a6a); d[1] = lds_read8a<O + 8>(a6a); d[2] = lds_read8a<O + 16>(a6a);
+      d[3] = lds_read8a<O + PL6>(a6a); d[4] = lds_read8a<O + PL6 + 8>(a6a); d[5] = lds_read8a<O + PL6 + 16>(a6a);
+    };
+    read_xy(std::integral_constant<int, 0>{}, xy[0]);
+    [&]<int... I>(std::integer_sequence<int, I...>) {
+      ([&] {
+        i32x2 (&cur)[6] = xy[I & 1];
+        if constexpr (I + 1 < TM) read_xy(std::integral_constant<int, I + 1>{}, xy[(I + 1) & 1]);
+        asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(cur[4]), "+v"(cur[5]) : "n"(I + 1 < TM ? 6 : 0));
+        __builtin_amdgcn_sched_barrier(0);
+        const i32x8 ax = {cur[0][0], cur[0][1], cur[1][0], cur[1][1], cur[2][0], cur[2][1], 0, 0};
+        const i32x8 ay = {cur[3][0], cur[3][1], cur[4][0], cur[4][1], cur[5][0], cur[5][1], 0, 0};
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[I][j] = mfma32_f6<e8m0(-kF6Act), e8m0(-kF6Wgt - kF8Lo)>(ax, cat6(wl6a[j], wl6c[j]), acc[I][j]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[I][j] = mfma32_f6<e8m0(-kF6Act - kF8Lo), e8m0(-kF6Wgt)>(ay, cat6(w6a[j], w6c[j]), acc[I][j]);
+        __builtin_amdgcn_sched_barrier(0);
+      }(), ...);
+    }(std::make_integer_sequence<int, TM>{});
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (PF) {
+      load_w6();
+      wait_vm<NW6>();
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if constexpr (PF) {
+      const int flip = (kt & 1) ? -STAGE : STAGE;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) a16a[ks] += flip;
+      a6a += flip;
+    }
+  };
+  for (int kt = 0; kt + 1 < ktiles; ++kt) ktile(std::true_type{}, kt);
+  ktile(std::false_type{}, ktiles - 1);
+
+  // ---- epilogue: as gemm_f8_kernel
+  constexpr int PITCH = 72;
+  float* patch = reinterpret_cast<float*>(smem) + wave * (32 * PITCH);
+  const int c8 = (lane & 7) * 8, r8 = lane >> 3;
+  const int em0 = m0, en = n0 + wc * 64 + c8;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) patch[((rr & 3) + 8 * (rr >> 2) + 4 * half) * PITCH + j * 32 + r32] = acc[i][j][rr];
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    float4 side[4][2];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      side[it][0] = load_side4<EPI>(g.out, em0 + i * 32 + r8 + 8 * it, en, g.M);
+      side[it][1] = load_side4<EPI>(g.out, em0 + i * 32 + r8 + 8 * it, en + 4, g.M);
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int rl = r8 + 8 * it;
+      const float4 v0 = *reinterpret_cast<const float4*>(patch + rl * PITCH + c8), v1 = *reinterpret_cast<const float4*>(patch + rl * PITCH + c8 + 4);
+      store_out8_f8<EPI>(g.out, em0 + i * 32 + rl, en, v0, v1, side[it][0], side[it][1], g.M);
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+}
+
+template <int EPI>
+int launch_f6(GemmArgs a, hipStream_t s) {
+  constexpr int lds = 2 * (128 * 64 * 2 + 2 * 128 * 48);     // 56 KB (>= the 36 KB of epilogue patches)
+  a.tiles_m = (a.M + 127) / 128;
+  a.tiles_n = a.N / 256;
+  a.group_n = 0; a.gm = g_gm;
+  AWT_ONCE_PER_DEVICE(AWT_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_f6_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)));
+  hipLaunchKernelGGL((gemm_f6_kernel<EPI>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
+  AWT_HIP_CHECK(hipGetLastError());
+  return AWT_OK;
+}
+
 int g_force_tile = 0;  // 0 = auto, 64 / 128 / 256 = forced (tuning and tests)
 // Tile order (see the kernel).  Measured on the encoder's shapes (tools/gemm_traffic_shapes.sh, profiles/r01_gemm_tile_order.txt):
 // column-tile groups of 3 cut the L2 -> fabric reads by 10 - 25 % but run 1.5 % slower end to end than groups of GM = 4 row
@@ -791,6 +1033,15 @@ int launch_one(GemmArgs a, hipStream_t s) {
 constexpr int kSlots = 512;
 template <int EPI>
 int launch_epi(GemmArgs a, int prec, hipStream_t s) {
+  if (prec == PREC_F16F6) {
+    if constexpr (EPI == EPI_F32 || EPI == EPI_F32_RESID) {
+      if (a.nseg != 1 || a.N % 256 != 0 || a.seg[0].rows_out != a.M || a.seg[0].rows_in != a.M || a.seg[0].row_mul != 1 || a.seg[0].row_add != 0)
+        return awt_fail(AWT_ERR_INVALID, "gemm (f16f6): one plain K segment and N % 256 == 0 only");
+      const int64_t gap = (const char*)a.seg[0].al8 - (const char*)a.seg[0].a8;
+      if (gap <= 0 || gap >= (1ll << 31)) return awt_fail(AWT_ERR_INVALID, "gemm (f16f6): the lo6 plane must follow the hi6 plane within 2 GB");
+      return launch_f6<EPI>(a, s);
+    } else return awt_fail(AWT_ERR_INVALID, "gemm (f16f6): fp32 outputs only (experimental single-operator path)");
+  }
   if (prec == PREC_F16F8) {
     if constexpr (EPI == EPI_BF16_GELU_SAVE || EPI == EPI_BF16_DGELU) return awt_fail(AWT_ERR_INVALID, "gemm: the training epilogues have no f16f8 form");
     else {
@@ -833,7 +1084,7 @@ int launch_gemm(awt_ctx* c, int M, int N, const GemmSeg* segs, int nseg, int pre
                 hipStream_t s) {
   AWT_REQUIRE(M > 0 && N > 0 && N % 128 == 0, AWT_ERR_INVALID, "gemm: N must be a positive multiple of 128");
   AWT_REQUIRE(nseg >= 1 && nseg <= kMaxSeg, AWT_ERR_INVALID, "gemm: 1..3 K-segments");
-  AWT_REQUIRE(prec == PREC_BF16 || prec == PREC_BF16X3 || prec == PREC_F16X3 || prec == PREC_F16F8, AWT_ERR_INVALID, "gemm: unknown operand precision");
+  AWT_REQUIRE(prec == PREC_BF16 || prec == PREC_BF16X3 || prec == PREC_F16X3 || prec == PREC_F16F8 || prec == PREC_F16F6, AWT_ERR_INVALID, "gemm: unknown operand precision");
   const int terms = prec_products(prec);
   AWT_REQUIRE(c && c->zeros, AWT_ERR_INVALID, "gemm: context without a zero page");
   static const bool env_read = [] { if (const char* e = getenv("AWT_GEMM_GROUP_N")) g_group_n = std::max(0, atoi(e)); return true; }();   // tile-order experiments (tools/)
@@ -844,7 +1095,7 @@ int launch_gemm(awt_ctx* c, int M, int N, const GemmSeg* segs, int nseg, int pre
   for (int i = 0; i < nseg; ++i) {
     a.seg[i] = segs[i];
     AWT_REQUIRE(segs[i].K > 0 && segs[i].K % 64 == 0, AWT_ERR_INVALID, "gemm: every K-segment must be a positive multiple of 64");
-    if (prec == PREC_F16F8) AWT_REQUIRE(segs[i].a_hi && segs[i].w_hi && segs[i].a8 && segs[i].al8 && segs[i].w8 && segs[i].wl8 && segs[i].w_ksteps % 2 == 0 && segs[i].w_k0 % 2 == 0,
+    if (prec == PREC_F16F8 || prec == PREC_F16F6) AWT_REQUIRE(segs[i].a_hi && segs[i].w_hi && segs[i].a8 && segs[i].al8 && segs[i].w8 && segs[i].wl8 && segs[i].w_ksteps % 2 == 0 && segs[i].w_k0 % 2 == 0,
                                         AWT_ERR_INVALID, "gemm (f16f8): null operand plane or a K-segment that is not 64-aligned in its weight matrix");
     else AWT_REQUIRE(segs[i].a_hi && segs[i].w_hi && (terms == 1 || (segs[i].a_lo && segs[i].w_lo)), AWT_ERR_INVALID, "gemm: null operand plane");
     AWT_REQUIRE(segs[i].lda % 8 == 0 && segs[i].w_ksteps > 0 && segs[i].w_k0 >= 0 && segs[i].w_k0 + segs[i].K / 32 <= segs[i].w_ksteps, AWT_ERR_INVALID,

@@ -126,3 +126,18 @@ def test_linear_output_larger_than_2g_elements():
     rows = torch.tensor([0, 1, 47999, 87380, 87382, M - 1], device="cuda")       # 87381 * 24576 ~ 2^31
     ref = torch.nn.functional.linear(x[rows].double(), w.double(), b.double())
     assert (y[rows].double() - ref).abs().max().item() < TOL["bf16x3"] * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 256, 64), (1000, 512, 768), (3000, 768, 3072), (257, 256, 128)])
+def test_linear_f16f6_experimental(M, N, K):
+    """The FP6 (e3m2) cross-term form of the GEMM, single-operator path only: fp16 main product + two block-scaled FP6 products.  Error of a
+    product ~2^-14 relative (2 mantissa bits on a term that is 2^-11 of the product)."""
+    from mlx8_ws_audio_transformer_amd import ops
+    x, w, b = _rand((M, K), 31), _rand((N, K), 32, K ** -0.5), _rand((N,), 33)
+    y = ops.linear(x, w, b, "f16f6")
+    ref = x.double() @ w.double().t() + b.double()
+    err = (y.double() - ref).abs().max().item()
+    y8 = ops.linear(x, w, b, "f16f8")
+    err8 = (y8.double() - ref).abs().max().item()
+    print((M, N, K), "f16f6", err, "f16f8", err8)
+    assert err < 3e-4 * max(1.0, (K / 768) ** 0.5), (err, err8)
