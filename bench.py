@@ -62,6 +62,10 @@ def parse():
     ap.add_argument("--chunk", type=int, default=0, help="clips per kernel wave inside the library (0 = default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fast-mode", action="store_true")
+    ap.add_argument("--weights", default="fp16", choices=["fp16", "fp32"],
+                    help="random-init weights rounded to fp16-representable values, as published Whisper checkpoints are (they are stored in half "
+                         "precision; default), or left as arbitrary fp32 values.  The library detects fp16-exact weights at upload and its f16f8 "
+                         "GEMMs then drop the x_hi w_lo cross term, which is exactly zero (DESIGN.md 4.2b); the other case is reported beside it")
     ap.add_argument("--no-power", action="store_true", help="do not start the rocm-smi sampler process (profiler runs: every child would be traced)")
     ap.add_argument("--cpu-clips", type=int, default=8)
     ap.add_argument("--workload", default="encode", choices=["encode", "sweep", "finetune", "noop"])
@@ -296,7 +300,8 @@ def sweep_main(a):
     from mlx8_ws_audio_transformer_amd.encoder import NativeWhisperEncoder
     cfg = wts.config(a.model, a.trimmed)
     pcm = torch.from_numpy(shard).to(dev)
-    enc = NativeWhisperEncoder(cfg, precision=a.precision, device=str(dev), chunk_clips=a.chunk, seed=0, init_profile="hf").eval()
+    enc = load_bench_weights(torch, NativeWhisperEncoder(cfg, precision=a.precision, device=str(dev), chunk_clips=a.chunk, seed=0, init_profile="hf").eval(),
+                             bench_weights(cfg, a.weights))
     for _ in range(max(1, a.warmup)):
         enc.encode_pcm(pcm[: a.batch])
     check = torch.zeros((), dtype=torch.float64, device=dev)
@@ -373,6 +378,22 @@ class PowerSampler:
             pass
 
 
+def bench_weights(cfg, kind):
+    """The deterministic random-init encoder weights of the bench (HF initialisation, seed 0); kind "fp16": every matrix rounded to fp16-representable
+    values (fp32 tensors holding half-precision values, like a checkpoint converted from a half-precision release)."""
+    import numpy as np
+    from mlx8_ws_audio_transformer_amd import weights as wts
+    W = wts.init_encoder_weights(cfg, 0, "hf")
+    if kind == "fp16":
+        W = {k: (v.astype(np.float16).astype(np.float32) if v.ndim >= 2 else v) for k, v in W.items()}
+    return W
+
+
+def load_bench_weights(torch, enc, W):
+    enc.load_state_dict({k: torch.from_numpy(v) for k, v in W.items()})
+    return enc
+
+
 def cpu_baseline_and_parity(a, torch, cfg, enc, pcm, pcm_host, out_first):
     """The oracle (CPU restatement of the reference path) on this host's cores: 1 warm-up + 3 timed passes over a bounded
     sample, median, for mel alone, encoder alone and end to end; then HIP vs oracle on the same clips."""
@@ -384,7 +405,7 @@ def cpu_baseline_and_parity(a, torch, cfg, enc, pcm, pcm_host, out_first):
     cap = int(os.environ.get("AWT_CPU_THREADS", "16"))     # the GPU box gives one GPU's share of the host: 16 cores
     ncpu = min(avail, cap)
     torch.set_num_threads(ncpu)
-    W = wts.init_encoder_weights(cfg, 0, "hf")
+    W = bench_weights(cfg, a.weights)
     clips_f32 = [synth.pcm_i16_to_f32(c) for c in pcm_host[:n]]
     t_mel, t_enc = [], []
     for it in range(4):                                     # pass 0 is the warm-up
@@ -447,7 +468,8 @@ def encode_main(a):
     # synthetic clips: this rank's contiguous shard of the seeded piano-note set
     pcm_host = synth.synth_clips_i16(B, seed=1234, first=rank * B)
     pcm = torch.from_numpy(pcm_host).to(dev)
-    enc = NativeWhisperEncoder(cfg, precision=a.precision, device=str(dev), chunk_clips=a.chunk, seed=0, init_profile="hf").eval()
+    enc = load_bench_weights(torch, NativeWhisperEncoder(cfg, precision=a.precision, device=str(dev), chunk_clips=a.chunk, seed=0, init_profile="hf").eval(),
+                             bench_weights(cfg, a.weights))
 
     for _ in range(a.warmup):
         enc.encode_pcm(pcm)
@@ -474,6 +496,8 @@ def encode_main(a):
     gemm_ms, gemm_n, gemm_flop = prof["gemm"]
     achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     terms = _lib.MFMA_PER_PAIR[a.precision]
+    if a.precision == "f16f8" and a.weights == "fp16":
+        terms = 1.5        # fp16-exact weights: fp16 product + ONE e4m3 cross term at twice the rate (the conv stem's two small GEMMs keep both)
     result = {
         "metric": "4s@16kHz clips/sec through mel+Whisper-%s encoder" % a.model,
         "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -483,7 +507,9 @@ def encode_main(a):
                                % (cfg.n_frames, a.model, cfg.max_source_positions, cfg.d_model),
                    "mode": "trimmed (NOT reference-equivalent)" if a.trimmed else "parity (clip zero-padded to 30 s, as the reference computes)",
                    "clips_per_gpu_per_step": B, "precision": a.precision,
-                   "mfma_products_per_fragment_pair": terms, "weights": "random-init Whisper-%s shape, seed 0" % a.model,
+                   "mfma_products_per_fragment_pair": terms, "weights": ("random-init Whisper-%s shape, seed 0, rounded to fp16-representable values as checkpoints released in half precision are "
+                                                                             "(the f16f8 GEMMs drop the then-zero x_hi w_lo cross term; `general_fp32_weights` is the other case)" % a.model)
+                   if a.weights == "fp16" else "random-init Whisper-%s shape, seed 0, arbitrary fp32 values" % a.model,
                    "parallelism": "dp%d (clip shards, no data-path collective)" % world},
         "roofline": {"bound": "mfma", "kernel": "gemm_kernel<%s> (all encoder GEMMs: conv stem, QKV, out, fc1, fc2)" % a.precision,
                      "achieved": round(achieved, 2), "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
@@ -523,7 +549,8 @@ def encode_main(a):
             for prec in PRECISIONS:
                 if prec == a.precision:
                     continue
-                other = NativeWhisperEncoder(cfg, precision=prec, device=str(dev), chunk_clips=a.chunk, seed=0, init_profile="hf").eval()
+                other = load_bench_weights(torch, NativeWhisperEncoder(cfg, precision=prec, device=str(dev), chunk_clips=a.chunk, seed=0, init_profile="hf").eval(),
+                                           bench_weights(cfg, a.weights))
                 for _ in range(max(1, a.warmup)):
                     other.encode_pcm(pcm)
                 fdt, _, fout = R.timed(lambda: other.encode_pcm(pcm), a.steps)
@@ -534,6 +561,15 @@ def encode_main(a):
                               "mfma_products_per_fragment_pair": _lib.MFMA_PER_PAIR[prec]}
                 del other
             result["other_precisions"] = side
+            if a.weights == "fp16" and a.precision == "f16f8":
+                # the same mode on weights that are NOT fp16-exact: the general two-cross-term GEMM
+                gen = NativeWhisperEncoder(cfg, precision=a.precision, device=str(dev), chunk_clips=a.chunk, seed=0, init_profile="hf").eval()
+                for _ in range(max(1, a.warmup)):
+                    gen.encode_pcm(pcm)
+                gdt, _, _ = R.timed(lambda: gen.encode_pcm(pcm), a.steps)
+                result["general_fp32_weights"] = {"value": round(B * a.steps / gdt, 2), "unit": "clips/s", "ms_per_step": round(gdt / a.steps * 1e3, 3),
+                                                  "note": "same build and mode, random-init weights left as arbitrary fp32 values: both cross terms of every GEMM"}
+                del gen
         # ---- CPU baseline: the oracle (CPU restatement of the reference path) on this host's cores, bounded sample
         if not a.no_cpu_baseline:
             result["cpu_baseline"], result["parity"], _ = cpu_baseline_and_parity(a, torch, cfg, enc, pcm, pcm_host, out)

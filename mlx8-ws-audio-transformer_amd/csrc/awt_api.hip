@@ -159,6 +159,9 @@ namespace {
 
 struct Planes {  // a weight matrix as operand planes owned by the library: hi (+ lo); f16f8: hi = fp16, lo = hi8 and x8 = lo8 planes
   bf16_t* hi = nullptr; bf16_t* lo = nullptr; uint8_t* x8 = nullptr; int64_t rows = 0, ld = 0;
+  // PREC_F16F8 inference: one device flag per separately uploaded row block (q | k | v): "a weight of this block is not exactly fp16";
+  // exact16 = no flag set = the lo8 image is all zero and the GEMM drops that cross term (gemm.hip, WX)
+  int* d_inexact = nullptr; bool exact16 = false;
 };
 struct Linear {
   Planes w; float* bias = nullptr; int N = 0, K = 0;
@@ -285,6 +288,7 @@ GemmSeg seg_plain(const Act& a, int64_t lda, const Planes& w, int64_t wcol, int 
   s.w_hi = w.hi; s.w_lo = w.lo; s.w8 = (const uint8_t*)w.lo; s.wl8 = w.x8;
   s.w_ksteps = (int)(w.ld / 32); s.w_k0 = (int)(wcol / 32); s.K = K;
   s.rows_out = M; s.rows_in = M; s.row_mul = 1; s.row_add = 0;
+  s.w_exact16 = w.exact16 ? 1 : 0;
   return s;
 }
 GemmSeg seg_plain(const bf16_t* a_hi, const bf16_t* a_lo, int64_t lda, const Planes& w, int64_t wcol, int K, int M) {   // bf16 planes (backward pass)
@@ -515,6 +519,8 @@ extern "C" int awt_encoder_create(awt_ctx* c, const awt_encoder_cfg* cfg, awt_en
     if (!rc) rc = alloc_linear(e, &L.out, d, d);
     if (!rc) rc = alloc_linear(e, &L.fc1, f, d);
     if (!rc) rc = alloc_linear(e, &L.fc2, d, f);
+    if (e->prec == PREC_F16F8 && !cfg->training)       // four zero-initialised "not fp16-exact" flags per projection matrix (set_weight)
+      for (Linear* lin : {&L.qkv, &L.out, &L.fc1, &L.fc2}) if (!rc) rc = dev_alloc(e, (void**)&lin->w.d_inexact, 4 * sizeof(int));
     if (cfg->training) {
       if (!rc) rc = alloc_planes(e, &L.qkvT, d, 3 * d);
       if (!rc) rc = alloc_planes(e, &L.outT, d, d);
@@ -573,7 +579,18 @@ extern "C" int awt_encoder_set_weight(awt_encoder* e, const char* name, const fl
     for (const Proj& p : projs) {
       const std::string key(p.key);
       if (rs == key + ".weight") {
-        found = true; rc = check_shape(name, shape, rank, {p.N, p.K}); if (!rc) rc = pack(p.lin->w, p.N, p.K, 1, p.row_off, 0);
+        found = true; rc = check_shape(name, shape, rank, {p.N, p.K});
+        if (!rc && e->prec == PREC_F16F8 && !c.training && p.lin->w.d_inexact) {
+          // fp16-exact weights (checkpoints stored in half precision) let the GEMM drop one cross term: find out now, at upload time
+          Planes& pl = p.lin->w;
+          int* flag = pl.d_inexact + p.row_off / p.N;
+          int host[4] = {0, 0, 0, 0};
+          if (hipMemsetAsync(flag, 0, sizeof(int), s) != hipSuccess) rc = awt_fail(AWT_ERR_HIP, "set_weight: flag reset failed");
+          if (!rc) rc = launch_pack_weight(e->ctx, data, p.N, p.K, 1, pl.ld, p.row_off, 0, 1.0f, pl.hi, pl.lo, pl.x8, e->prec, s, flag);
+          if (!rc && (hipMemcpyAsync(host, pl.d_inexact, sizeof(host), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess))
+            rc = awt_fail(AWT_ERR_HIP, "set_weight: flag read-back failed");
+          if (!rc) pl.exact16 = !(host[0] | host[1] | host[2] | host[3]);
+        } else if (!rc) rc = pack(p.lin->w, p.N, p.K, 1, p.row_off, 0);
         if (!rc && c.training)   // W^T: [K, N_total], this projection's columns start at row_off
           rc = launch_pack_weight_t(e->ctx, data, p.N, p.K, p.wT->ld, 0, p.row_off, 1.0f, p.wT->hi, p.wT->lo, s);
       }
@@ -680,7 +697,7 @@ extern "C" int awt_audio_encode(awt_encoder* e, const void* pcm, int pcm_is_i16,
 
 // ------------------------------------------------------------------------------------------------ single operators
 extern "C" size_t awt_op_linear_workspace_bytes(int M, int N, int K) {
-  return 2 * align_up((size_t)M * K * 2) + 2 * align_up((size_t)N * K * 2);
+  return 2 * align_up((size_t)M * K * 2) + 2 * align_up((size_t)N * K * 2) + 256;     // + a flag word (fp16-exact weights)
 }
 extern "C" int awt_op_linear(awt_ctx* c, const float* x, const float* w, const float* bias, float* y, int M, int N, int K,
                              int terms, void* workspace, size_t ws_bytes, void* stream) {
@@ -706,8 +723,18 @@ extern "C" int awt_op_linear(awt_ctx* c, const float* x, const float* w, const f
   }
   const Act ax = make_act(xh, xl, (size_t)M * K, terms);
   int rc = launch_split_planes(c, x, (int64_t)M * K, 1.0f, terms, kF8Act, xh, xl, ax.hi8, ax.lo8, s); if (rc) return rc;
-  rc = launch_pack_weight(c, w, N, K, 1, K, 0, 0, 1.0f, wh, wl, (uint8_t*)wl + (size_t)N * K, terms, s); if (rc) return rc;     // fragment-major
   Planes pw; pw.hi = wh; pw.lo = wl; pw.x8 = (uint8_t*)wl + (size_t)N * K; pw.rows = N; pw.ld = K;
+  if (terms == PREC_F16F8) {   // as awt_encoder_set_weight does: fp16-exact weights take the one-cross-term GEMM; the flag is the
+    int* flag = (int*)((char*)wl + align_up((size_t)N * K * 2));      // word of the workspace's 256-byte tail
+    int host = 1;
+    if (hipMemsetAsync(flag, 0, sizeof(int), s) != hipSuccess) return awt_fail(AWT_ERR_HIP, "op_linear: flag reset failed");
+    rc = launch_pack_weight(c, w, N, K, 1, K, 0, 0, 1.0f, wh, wl, pw.x8, terms, s, flag); if (rc) return rc;
+    if (hipMemcpyAsync(&host, flag, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+      return awt_fail(AWT_ERR_HIP, "op_linear: flag read-back failed");
+    pw.exact16 = host == 0;
+  } else {
+    rc = launch_pack_weight(c, w, N, K, 1, K, 0, 0, 1.0f, wh, wl, pw.x8, terms, s); if (rc) return rc;     // fragment-major
+  }
   GemmSeg sg = seg_plain(ax, K, pw, 0, K, M);
   GemmOut o{}; o.f32 = y; o.ldo = N; o.bias = bias; o.n_valid = N;
   return launch_gemm(c, M, N, &sg, 1, terms, EPI_F32, o, s);

@@ -249,6 +249,7 @@ struct GemmSeg {
   // PREC_F16F8: a_hi / w_hi are the fp16 planes, a_lo / w_lo are unused, and these are the e4m3 planes (activations row-major
   // with the same lda, weights in w8_index order; w_ksteps / w_k0 still count 32-deep steps of the matrix / of the segment start)
   const uint8_t* a8; const uint8_t* al8; const uint8_t* w8; const uint8_t* wl8;
+  int w_exact16;                                         // PREC_F16F8: every weight of the segment is exactly representable in fp16 (its lo8 image is zero)
   int K;                                                 // multiple of the kernel's BK
   // source row of output row m:  (m / rows_out) * rows_in + (m % rows_out) * row_mul + row_add ; rows outside
   // [0, rows_in) of their group read as zeros (the conv stem's padding).  Plain GEMM: rows_out = rows_in = M.
@@ -307,7 +308,7 @@ int launch_attention_f16f8(awt_ctx* c, const F8Planes& q, const F8Planes& k, con
 int launch_split_planes_f6(awt_ctx* c, const float* x, int M, int K, bf16_t* p16, uint8_t* hi6, uint8_t* lo6, hipStream_t s);
 int launch_pack_weight_f6(awt_ctx* c, const float* w, int N, int K, bf16_t* w16, uint8_t* hi6, uint8_t* lo6, hipStream_t s);
 int launch_pack_weight(awt_ctx* c, const float* src, int N, int C, int taps, int64_t ld, int row_off, int col_off, float scale,
-                       bf16_t* hi, bf16_t* lo, uint8_t* lo8, int prec, hipStream_t s);
+                       bf16_t* hi, bf16_t* lo, uint8_t* lo8, int prec, hipStream_t s, int* inexact = nullptr);   // inexact (PREC_F16F8, device int): set to 1 when a weight is not fp16-exact
 // conv1 im2col: mel f32 [B, C, T] -> A [B*T, K_dst] bf16 hi/lo, k = dt * C + c reads mel[b, c, t + dt - 1]
 int launch_im2col_conv1(awt_ctx* c, const float* mel, int B, int C, int T, int K_dst, const Act& out, int prec, hipStream_t s);
 

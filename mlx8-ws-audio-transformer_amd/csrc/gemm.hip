@@ -478,15 +478,19 @@ __device__ __forceinline__ i32x8 cat8(bf16x8 lo, bf16x8 hi) {
   return __builtin_shufflevector(__builtin_bit_cast(i32x4_t, lo), __builtin_bit_cast(i32x4_t, hi), 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <int EPI, class CFG, bool MULTI>
+// WX: every weight of the (single) K segment is exactly representable in fp16 (true of checkpoints stored in half precision), so its lo plane is
+// zero and the x_hi w_lo cross term vanishes: one e4m3 MFMA per fragment pair (x_lo8 w_hi8) instead of two, and neither the A hi8 image nor the W lo8
+// image is moved at all -- 1.5 instead of 2 bf16-MFMA-equivalents and 3 instead of 4 operand bytes per element, with the same result to rounding.
+template <int EPI, class CFG, bool MULTI, bool WX = false>
 __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, CFG::WM * CFG::WN == 4 ? 2 : 1) void gemm_f8_kernel(GemmArgs g) {
   constexpr int WM = CFG::WM, WN = CFG::WN, TM = CFG::TM, TN = CFG::TN;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32, BK = 64, NT = WM * WN * 64;
   static_assert((BM == 128 && NT == 256) || (BM == 256 && NT == 512), "128 rows per four waves");
   constexpr int PL16 = BM * BK * 2, PL8 = BM * BK, STAGE = PL16 + 2 * PL8;     // 16 + 8 + 8 KB per 128 rows
   constexpr int IT16 = PL16 / 16 / NT, IT8 = PL8 / 16 / NT;                     // LDS-DMA pieces per thread: 4, 2 (+ 2)
-  constexpr int NDMA = IT16 + 2 * IT8;                                          // 8
-  constexpr int NW16 = 4 * TN, NW8 = 4 * TN;                                    // W loads per lane per K-tile: fp16 (4 k-steps x TN), e4m3 (2 planes x TN x 2)
+  static_assert(!(WX && MULTI), "the exact-weight form is single-segment");
+  constexpr int NDMA = IT16 + (WX ? 1 : 2) * IT8;                               // 8 (6)
+  constexpr int NW16 = 4 * TN, NW8 = (WX ? 2 : 4) * TN;                                    // W loads per lane per K-tile: fp16 (4 k-steps x TN), e4m3 (2 planes x TN x 2)
   constexpr unsigned kInvalid = 0xFFFFFFFFu;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -573,12 +577,13 @@ __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, CFG::WM * CFG::WN == 4 ? 2 
     if constexpr (OP < IT16) {
       const unsigned o = a16o[OP];
       glds16(o != kInvalid ? (const void*)(a16b + o) : (const void*)g.zeros, stage + (OP * NT + wave * 64) * 16);
-    } else if constexpr (OP < IT16 + IT8) {
+    } else if constexpr (OP < IT16 + IT8 && !WX) {
       const unsigned o = a8o[OP - IT16];
       glds16(o != kInvalid ? (const void*)(a8b + o) : (const void*)g.zeros, stage + PL16 + ((OP - IT16) * NT + wave * 64) * 16);
     } else {
-      const unsigned o = a8o[OP - IT16 - IT8];
-      glds16(o != kInvalid ? (const void*)(al8b + o) : (const void*)g.zeros, stage + PL16 + PL8 + ((OP - IT16 - IT8) * NT + wave * 64) * 16);
+      constexpr int P8 = OP - IT16 - (WX ? 0 : IT8);
+      const unsigned o = a8o[P8];
+      glds16(o != kInvalid ? (const void*)(al8b + o) : (const void*)g.zeros, stage + PL16 + PL8 + (P8 * NT + wave * 64) * 16);
     }
   };
 
@@ -593,7 +598,7 @@ __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, CFG::WM * CFG::WN == 4 ? 2 
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       w8[j][0] = gload16<0>(wl32, w8b[j]); w8[j][1] = gload16<16>(wl32, w8b[j]);
-      wl8[j][0] = gload16<0>(wl32, wl8b[j]); wl8[j][1] = gload16<16>(wl32, wl8b[j]);
+      if constexpr (!WX) { wl8[j][0] = gload16<0>(wl32, wl8b[j]); wl8[j][1] = gload16<16>(wl32, wl8b[j]); }
     }
   };
 
@@ -643,19 +648,25 @@ __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, CFG::WM * CFG::WN == 4 ? 2 
     auto read_x = [&](auto i_t) { constexpr int O = STG * STAGE + decltype(i_t)::value * 32 * 64; ax[0] = lds_read16<O>(a8a[0]); ax[1] = lds_read16<O>(a8a[1]); };
     auto read_y = [&](auto i_t) { constexpr int O = STG * STAGE + decltype(i_t)::value * 32 * 64 + PL8; ay[0] = lds_read16<O>(a8a[0]); ay[1] = lds_read16<O>(a8a[1]); };
     constexpr bool EARLY8 = !MULTI;
+    // WX: only the lo8 image is read; row tile I + 1 is read before the MFMAs of row tile I into the other of the two fragment buffers (ax idles)
+    auto read_yb = [&](auto i_t) {
+      constexpr int I = decltype(i_t)::value, O = STG * STAGE + I * 32 * 64 + PL8;
+      if constexpr (I & 1) { ax[0] = lds_read16<O>(a8a[0]); ax[1] = lds_read16<O>(a8a[1]); }
+      else { ay[0] = lds_read16<O>(a8a[0]); ay[1] = lds_read16<O>(a8a[1]); }
+    };
     [&]<int... S>(std::integer_sequence<int, S...>) {
       ([&] {
         constexpr int ks = S / TM, i = S % TM;
         if constexpr (S + AD < 4 * TM) read_a16(std::integral_constant<int, S + AD>{});
-        if constexpr (EARLY8 && S == 4 * TM - 2) read_x(std::integral_constant<int, 0>{});
-        if constexpr (EARLY8 && S == 4 * TM - 1) read_y(std::integral_constant<int, 0>{});
+        if constexpr (EARLY8 && !WX && S == 4 * TM - 2) read_x(std::integral_constant<int, 0>{});
+        if constexpr (EARLY8 && S == 4 * TM - 1) { if constexpr (WX) read_yb(std::integral_constant<int, 0>{}); else read_y(std::integral_constant<int, 0>{}); }
         if constexpr (PF && ks == 0) {
           [&]<int... O>(std::integer_sequence<int, O...>) {
             ([&] { constexpr int op = i * DMA_PER_STEP + O; if constexpr (op < NDMA) dma(std::integral_constant<int, op>{}, nxt); }(), ...);
           }(std::make_integer_sequence<int, DMA_PER_STEP>{});
         }
         // LDS operations younger than this step's fragment: the (up to) three fragments read ahead, plus the first e4m3 reads
-        constexpr int AHEAD = (4 * TM - 1 - S < AD ? 4 * TM - 1 - S : AD) + (EARLY8 && S >= 4 * TM - 2 ? 2 : 0) + (EARLY8 && S >= 4 * TM - 1 ? 2 : 0);
+        constexpr int AHEAD = (4 * TM - 1 - S < AD ? 4 * TM - 1 - S : AD) + (EARLY8 && !WX && S >= 4 * TM - 2 ? 2 : 0) + (EARLY8 && S >= 4 * TM - 1 ? 2 : 0);
         lgkm_wait<AHEAD>(af[S % (AD + 1)]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -666,23 +677,36 @@ __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, CFG::WM * CFG::WN == 4 ? 2 
     }(std::make_integer_sequence<int, 4 * TM>{});
     // ---- e4m3 part: its W registers were loaded a K-tile ago, behind this K-tile's NDMA + NW16 younger operations
     if constexpr (PF) wait_vm<NDMA + NW16>(); else wait_vm<0>();
-    if constexpr (!EARLY8) { read_x(std::integral_constant<int, 0>{}); read_y(std::integral_constant<int, 0>{}); }
+    if constexpr (!EARLY8) { if constexpr (!WX) read_x(std::integral_constant<int, 0>{}); read_y(std::integral_constant<int, 0>{}); }
     [&]<int... I>(std::integer_sequence<int, I...>) {
       ([&] {
-        lgkm_wait<2>(ax[0], ax[1]);                       // younger: Y(I)
-        __builtin_amdgcn_sched_barrier(0);
-        const i32x8 a8 = cat8(ax[0], ax[1]);
+        if constexpr (!WX) {
+          lgkm_wait<2>(ax[0], ax[1]);                     // younger: Y(I)
+          __builtin_amdgcn_sched_barrier(0);
+          const i32x8 a8 = cat8(ax[0], ax[1]);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[I][j] = mfma32_f8<e8m0(-kF8Act), e8m0(-kF8Wgt - kF8Lo)>(a8, cat8(wl8[j][0], wl8[j][1]), acc[I][j]);
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (I + 1 < TM) read_x(std::integral_constant<int, I + 1>{});
-        lgkm_wait<(I + 1 < TM ? 2 : 0)>(ay[0], ay[1]);    // younger: X(I + 1)
-        __builtin_amdgcn_sched_barrier(0);
-        const i32x8 al8 = cat8(ay[0], ay[1]);
+          for (int j = 0; j < TN; ++j) acc[I][j] = mfma32_f8<e8m0(-kF8Act), e8m0(-kF8Wgt - kF8Lo)>(a8, cat8(wl8[j][0], wl8[j][1]), acc[I][j]);
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (I + 1 < TM) read_x(std::integral_constant<int, I + 1>{});
+        }
+        if constexpr (WX) {
+          if constexpr (I + 1 < TM) read_yb(std::integral_constant<int, I + 1>{});
+          bf16x8 (&yb)[2] = (I & 1) ? ax : ay;
+          lgkm_wait<(I + 1 < TM ? 2 : 0)>(yb[0], yb[1]);    // younger: Y(I + 1)
+          __builtin_amdgcn_sched_barrier(0);
+          const i32x8 al8 = cat8(yb[0], yb[1]);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[I][j] = mfma32_f8<e8m0(-kF8Act - kF8Lo), e8m0(-kF8Wgt)>(al8, cat8(w8[j][0], w8[j][1]), acc[I][j]);
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (I + 1 < TM) read_y(std::integral_constant<int, I + 1>{});
+          for (int j = 0; j < TN; ++j) acc[I][j] = mfma32_f8<e8m0(-kF8Act - kF8Lo), e8m0(-kF8Wgt)>(al8, cat8(w8[j][0], w8[j][1]), acc[I][j]);
+          __builtin_amdgcn_sched_barrier(0);
+        } else {
+          lgkm_wait<(I + 1 < TM ? 2 : 0)>(ay[0], ay[1]);    // younger: X(I + 1)
+          __builtin_amdgcn_sched_barrier(0);
+          const i32x8 al8 = cat8(ay[0], ay[1]);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[I][j] = mfma32_f8<e8m0(-kF8Act - kF8Lo), e8m0(-kF8Wgt)>(al8, cat8(w8[j][0], w8[j][1]), acc[I][j]);
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (I + 1 < TM) read_y(std::integral_constant<int, I + 1>{});
+        }
       }(), ...);
     }(std::make_integer_sequence<int, TM>{});
     if constexpr (PF) {
@@ -754,7 +778,10 @@ int launch_f8(GemmArgs a, hipStream_t s) {
   a.tiles_m = (a.M + BM - 1) / BM;
   a.tiles_n = (a.N + BN - 1) / BN;
   a.group_n = 0; a.gm = g_gm;
-  if (a.nseg == 1) {
+  if (a.nseg == 1 && a.seg[0].w_exact16) {
+    AWT_ONCE_PER_DEVICE(AWT_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_f8_kernel<EPI, CFG, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)));
+    hipLaunchKernelGGL((gemm_f8_kernel<EPI, CFG, false, true>), dim3(a.tiles_m * a.tiles_n), dim3(CFG::WM * CFG::WN * 64), lds, s, a);
+  } else if (a.nseg == 1) {
     AWT_ONCE_PER_DEVICE(AWT_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_f8_kernel<EPI, CFG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)));
     hipLaunchKernelGGL((gemm_f8_kernel<EPI, CFG, false>), dim3(a.tiles_m * a.tiles_n), dim3(CFG::WM * CFG::WN * 64), lds, s, a);
   } else {

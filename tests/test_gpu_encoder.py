@@ -278,3 +278,25 @@ def test_default_precision_follows_the_checkpoint():
     explicit.load_state_dict({k: torch.from_numpy(v) for k, v in W.items()})
     explicit(torch.from_numpy(mel).cuda())
     assert explicit.precision == "f16f8"
+
+
+@pytest.mark.parametrize("name,trimmed,batch", [("tiny", True, 2), ("small", False, 1)])
+def test_fp16_exact_checkpoint_takes_the_one_cross_term_gemm_and_keeps_parity(name, trimmed, batch):
+    """Checkpoints stored in half precision hold weights that are exactly fp16: their lo planes are zero, the library detects it when the
+    weights are uploaded and its f16f8 GEMMs drop that cross term.  Parity against the oracle ON THE SAME WEIGHTS stays inside the bound and
+    at the level of the general path; loading weights that are not fp16-exact switches back."""
+    cfg = wts.config(name, trimmed)
+    W = wts.init_encoder_weights(cfg, 0, "hf")
+    W16 = {k: (v.astype(np.float16).astype(np.float32) if v.ndim >= 2 else v) for k, v in W.items()}
+    mel = _mel(cfg, batch)
+    enc = _native(cfg, "f16f8", profile="hf")
+    out_general = enc(torch.from_numpy(mel).cuda()).last_hidden_state.cpu().numpy()
+    e_general = oracle_enc.error_norms(out_general, oracle_enc.encoder_forward(W, mel, cfg.heads, dtype=torch.float64).numpy())
+    enc.load_state_dict({k: torch.from_numpy(v) for k, v in W16.items()})
+    out16 = enc(torch.from_numpy(mel).cuda()).last_hidden_state.cpu().numpy()
+    e16 = oracle_enc.error_norms(out16, oracle_enc.encoder_forward(W16, mel, cfg.heads, dtype=torch.float64).numpy())
+    print(name, "general", e_general, "fp16-exact weights", e16)
+    assert e16["max_abs"] < 1e-3 and e16["max_abs"] < 3 * e_general["max_abs"] + 2e-5
+    enc.load_state_dict({k: torch.from_numpy(v) for k, v in W.items()})                      # back to weights with non-zero lo planes
+    again = enc(torch.from_numpy(mel).cuda()).last_hidden_state.cpu().numpy()
+    assert np.array_equal(again, out_general)

@@ -141,3 +141,22 @@ def test_linear_f16f6_experimental(M, N, K):
     err8 = (y8.double() - ref).abs().max().item()
     print((M, N, K), "f16f6", err, "f16f8", err8)
     assert err < 3e-4 * max(1.0, (K / 768) ** 0.5), (err, err8)
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 256, 64), (1500, 768, 768), (3000, 768, 3072), (700, 384, 1536), (96, 2304, 768)])
+def test_linear_f16f8_with_fp16_exact_weights(M, N, K):
+    """Weights that are exactly representable in fp16 (what checkpoints stored in half precision hold) have a zero lo plane: the library
+    notices at upload time and runs the GEMM with ONE e4m3 cross term (x_lo w_hi) instead of two.  Same accuracy class as the general
+    path, which the same call takes for weights that are not fp16-exact."""
+    from mlx8_ws_audio_transformer_amd import ops
+    x, w, b = _rand((M, K), 41), _rand((N, K), 42, K ** -0.5), _rand((N,), 43)
+    w16 = w.half().float()
+    assert not torch.equal(w16, w)
+    ref16 = x.double() @ w16.double().t() + b.double()
+    ref = x.double() @ w.double().t() + b.double()
+    y16 = ops.linear(x, w16, b, "f16f8")            # exact weights: one cross term
+    y = ops.linear(x, w, b, "f16f8")                # general path
+    e16, e = (y16.double() - ref16).abs().max().item(), (y.double() - ref).abs().max().item()
+    print((M, N, K), "exact-weight path", e16, "general path", e)
+    tol = 1e-4 * max(1.0, (K / 768) ** 0.5)          # outputs are O(1); K = 64 has the largest weights (K^-1/2)
+    assert e16 < tol and e < tol and e16 < 1.5 * e + 1e-5
