@@ -136,7 +136,10 @@ void awt_encoder_destroy(awt_encoder* e);
  * `layers.{i}.self_attn.{q,k,v,out}_proj.{weight,bias}`, `layers.{i}.{self_attn_layer_norm,final_layer_norm}.*`,
  * `layers.{i}.fc{1,2}.*`, `layer_norm.*`, `embed_positions.weight`, plus build-defined `<module>.lora_A` [r, in] and
  * `<module>.lora_B` [out, r].  `data` is a float32 device pointer of `rank`-d `shape`; the library converts it to
- * its internal bf16 (hi / lo) layout on `stream` and keeps its own copy. */
+ * its internal operand planes on `stream` and keeps its own copy.  In the f16f8 inference format the upload of a
+ * projection matrix (q / k / v / out_proj / fc1 / fc2) also finds out whether every element is exactly representable in
+ * fp16 -- true of checkpoints released in half precision -- and, to read that one flag back, synchronises `stream`;
+ * such a matrix's GEMM then drops the identically-zero x_hi w_lo cross term. */
 int awt_encoder_set_weight(awt_encoder* e, const char* hf_name, const float* data, const int64_t* shape, int rank,
                            void* stream);
 
