@@ -302,7 +302,7 @@ __global__ __launch_bounds__(64 * NW, (QT == 1 && NW == 6) ? 3 : 2) void attenti
             uint2 h16; unsigned hi8, lo8;
             f16f8x4<kF8Act>(v, h16, hi8, lo8);
             *reinterpret_cast<uint2*>(a.o16 + row + e) = h16;
-            *reinterpret_cast<unsigned*>(a.o8 + row + e) = hi8;
+            if (a.o8) *reinterpret_cast<unsigned*>(a.o8 + row + e) = hi8;
             *reinterpret_cast<unsigned*>(a.ol8 + row + e) = lo8;
           }
         }
@@ -625,7 +625,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f16f8_pipe_kernel(Attn8A
           uint2 h16; unsigned hi8, lo8;
           f16f8x4<kF8Act>(v, h16, hi8, lo8);
           *reinterpret_cast<uint2*>(a.o16 + row + e) = h16;
-          *reinterpret_cast<unsigned*>(a.o8 + row + e) = hi8;
+          if (a.o8) *reinterpret_cast<unsigned*>(a.o8 + row + e) = hi8;
           *reinterpret_cast<unsigned*>(a.ol8 + row + e) = lo8;
         }
       }
@@ -663,7 +663,7 @@ int launch_attention_f16f8(awt_ctx* c, const F8Planes& q, const F8Planes& k, con
                            float* lse, int B, int H, int S, hipStream_t s) {
   AWT_REQUIRE(B > 0 && H > 0 && S > 0, AWT_ERR_INVALID, "attention: bad shape");
   AWT_REQUIRE(q.p16 && q.hi8 && q.lo8 && k.p16 && k.hi8 && k.lo8 && v.p16 && v.hi8 && v.lo8, AWT_ERR_INVALID, "attention (f16f8): null plane");
-  AWT_REQUIRE(o_f32 || (o.p16 && o.hi8 && o.lo8), AWT_ERR_INVALID, "attention (f16f8): null output plane");
+  AWT_REQUIRE(o_f32 || (o.p16 && o.lo8), AWT_ERR_INVALID, "attention (f16f8): null output plane (hi8 may be null: not consumed)");
   Attn8Args a{q.p16, k.p16, v.p16, q.hi8, q.lo8, k.hi8, k.lo8, v.hi8, v.lo8, o.p16, o.hi8, o.lo8, o_f32, lse, B, H, S};
   ProfScope prof(c, AWT_PROF_ATTENTION, s, 4.0 * (double)B * H * (double)S * S * 64);
   // shapes (awt_tuning_set "attn_shape"): 0 = auto; 1 = 4 waves x 32 queries; 2 = 4 waves x 64 queries; 3 = 6 waves x 32 queries

@@ -407,8 +407,10 @@ int encoder_layer(awt_encoder* e, Layer& L, const LayerBufs& b, int Bc, bool sav
   const int S = c.n_ctx, d = c.d_model, f = c.ffn_dim, H = c.n_heads, terms = e->prec;
   const int M = Bc * S;
   const int64_t plane = (int64_t)M * d;
-  const Act aqkv = make_act(b.qkv[0], b.qkv[1], 3 * (size_t)plane, terms), aatt = make_act(b.att[0], b.att[1], (size_t)plane, terms);
-  int rc = launch_layernorm(e->ctx, b.x_in, L.ln1_g, L.ln1_b, M, d, 1e-5f, nullptr, make_act(b.ln1[0], b.ln1[1], (size_t)plane, terms), terms, s); if (rc) return rc;
+  // an activation whose only consumer is a GEMM on fp16-exact weights (gemm.hip, WX) needs no hi8 image: the producers skip that plane
+  auto feeds = [&](Act a, const Linear& lin, const LoraGroup& lg) { if (terms == PREC_F16F8 && lin.w.exact16 && !lg.active) a.hi8 = nullptr; return a; };
+  const Act aqkv = make_act(b.qkv[0], b.qkv[1], 3 * (size_t)plane, terms), aatt = feeds(make_act(b.att[0], b.att[1], (size_t)plane, terms), L.out, L.lo_);
+  int rc = launch_layernorm(e->ctx, b.x_in, L.ln1_g, L.ln1_b, M, d, 1e-5f, nullptr, feeds(make_act(b.ln1[0], b.ln1[1], (size_t)plane, terms), L.qkv, L.lq), terms, s); if (rc) return rc;
   {
     GemmOut o{}; set_out(o, aqkv); o.scale = 0.125f * 1.4426950408889634f;   // head_dim^-1/2 and log2(e): see attention.hip
     o.S = S; o.H = H; o.plane_stride = plane;
@@ -427,9 +429,9 @@ int encoder_layer(awt_encoder* e, Layer& L, const LayerBufs& b, int Bc, bool sav
     GemmOut o{}; o.f32 = b.x_mid; o.resid = b.x_in; o.ldo = d;
     rc = linear_with_lora(e, b.uo, b.att, d, L.out, L.lo_, M, EPI_F32_RESID, o, s); if (rc) return rc;
   }
-  rc = launch_layernorm(e->ctx, b.x_mid, L.ln2_g, L.ln2_b, M, d, 1e-5f, nullptr, make_act(b.ln2[0], b.ln2[1], (size_t)plane, terms), terms, s); if (rc) return rc;
+  rc = launch_layernorm(e->ctx, b.x_mid, L.ln2_g, L.ln2_b, M, d, 1e-5f, nullptr, feeds(make_act(b.ln2[0], b.ln2[1], (size_t)plane, terms), L.fc1, L.l1), terms, s); if (rc) return rc;
   {
-    GemmOut o{}; set_out(o, make_act(b.ff[0], b.ff[1], (size_t)M * f, terms)); o.ldo = f; o.hi2 = b.pre[0]; o.lo2 = b.pre[1];
+    GemmOut o{}; set_out(o, feeds(make_act(b.ff[0], b.ff[1], (size_t)M * f, terms), L.fc2, L.l2)); o.ldo = f; o.hi2 = b.pre[0]; o.lo2 = b.pre[1];
     rc = linear_with_lora(e, b.u1, b.ln2, d, L.fc1, L.l1, M, save ? EPI_BF16_GELU_SAVE : EPI_BF16_GELU, o, s); if (rc) return rc;
   }
   GemmOut o{}; o.f32 = b.x_out; o.resid = b.x_mid; o.ldo = d;

@@ -177,7 +177,7 @@ __device__ __forceinline__ void store_act4(const Act& o, int64_t off, const floa
     uint2 h16; unsigned hi8, lo8;
     f16f8x4<S>(v, h16, hi8, lo8);
     *reinterpret_cast<uint2*>(o.p16 + off) = h16;
-    *reinterpret_cast<unsigned*>(o.hi8 + off) = hi8;
+    if (o.hi8) *reinterpret_cast<unsigned*>(o.hi8 + off) = hi8;      // null: every consumer runs the fp16-exact-weight GEMM, which never reads this image
     *reinterpret_cast<unsigned*>(o.lo8 + off) = lo8;
   } else {
     bf16_t h[4], l[4];

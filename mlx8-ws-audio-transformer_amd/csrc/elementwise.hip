@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256) void planes_f6_kernel(const float* __restrict_
 int launch_layernorm(awt_ctx* c, const float* x, const float* gamma, const float* beta, int M, int d, float eps,
                      float* out_f32, const Act& out, int prec, hipStream_t s) {
   AWT_REQUIRE(x && gamma && beta && (out_f32 || out.p16), AWT_ERR_INVALID, "layernorm: null argument");
-  AWT_REQUIRE(out_f32 || prec != PREC_F16F8 || (out.hi8 && out.lo8), AWT_ERR_INVALID, "layernorm: f16f8 output needs both e4m3 planes");
+  AWT_REQUIRE(out_f32 || prec != PREC_F16F8 || out.lo8, AWT_ERR_INVALID, "layernorm: f16f8 output needs its lo8 plane (hi8 may be null: not consumed)");
   AWT_REQUIRE(M > 0 && d > 0 && d % 4 == 0 && d <= 64 * 4 * kLnMaxChunks, AWT_ERR_INVALID, "layernorm: d must be a multiple of 4 and <= 1280");
   ProfScope prof(c, AWT_PROF_LAYERNORM, s, 0.0);
   const dim3 grid((M + 3) / 4), block(256);

@@ -278,7 +278,7 @@ __device__ __forceinline__ void store_out8_f8(const GemmOut& o, int m, int n, fl
 #pragma unroll
   for (int t = 0; t < 8; ++t) { h[t] = f32_to_f16(v[t]); l[t] = (v[t] - f16_to_f32(h[t])) * (f8s * pow2f(kF8Lo)); v[t] *= f8s; }
   *reinterpret_cast<uint4*>(o.hi + off) = make_uint4(pack2(h[0], h[1]), pack2(h[2], h[3]), pack2(h[4], h[5]), pack2(h[6], h[7]));
-  *reinterpret_cast<uint2*>(o.hi8 + off) = make_uint2(fp8x4<0>(v[0], v[1], v[2], v[3]), fp8x4<0>(v[4], v[5], v[6], v[7]));
+  if (o.hi8) *reinterpret_cast<uint2*>(o.hi8 + off) = make_uint2(fp8x4<0>(v[0], v[1], v[2], v[3]), fp8x4<0>(v[4], v[5], v[6], v[7]));   // null: see store_act4
   *reinterpret_cast<uint2*>(o.lo8 + off) = make_uint2(fp8x4<0>(l[0], l[1], l[2], l[3]), fp8x4<0>(l[4], l[5], l[6], l[7]));
 }
 
@@ -1122,7 +1122,7 @@ int launch_gemm(awt_ctx* c, int M, int N, const GemmSeg* segs, int nseg, int pre
   for (int i = 0; i < nseg; ++i) {
     a.seg[i] = segs[i];
     AWT_REQUIRE(segs[i].K > 0 && segs[i].K % 64 == 0, AWT_ERR_INVALID, "gemm: every K-segment must be a positive multiple of 64");
-    if (prec == PREC_F16F8 || prec == PREC_F16F6) AWT_REQUIRE(segs[i].a_hi && segs[i].w_hi && segs[i].a8 && segs[i].al8 && segs[i].w8 && segs[i].wl8 && segs[i].w_ksteps % 2 == 0 && segs[i].w_k0 % 2 == 0,
+    if (prec == PREC_F16F8 || prec == PREC_F16F6) AWT_REQUIRE(segs[i].a_hi && segs[i].w_hi && (segs[i].a8 || (segs[i].w_exact16 && nseg == 1 && prec == PREC_F16F8)) && segs[i].al8 && segs[i].w8 && segs[i].wl8 && segs[i].w_ksteps % 2 == 0 && segs[i].w_k0 % 2 == 0,
                                         AWT_ERR_INVALID, "gemm (f16f8): null operand plane or a K-segment that is not 64-aligned in its weight matrix");
     else AWT_REQUIRE(segs[i].a_hi && segs[i].w_hi && (terms == 1 || (segs[i].a_lo && segs[i].w_lo)), AWT_ERR_INVALID, "gemm: null operand plane");
     AWT_REQUIRE(segs[i].lda % 8 == 0 && segs[i].w_ksteps > 0 && segs[i].w_k0 >= 0 && segs[i].w_k0 + segs[i].K / 32 <= segs[i].w_ksteps, AWT_ERR_INVALID,
