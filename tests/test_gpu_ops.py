@@ -160,3 +160,19 @@ def test_linear_f16f8_with_fp16_exact_weights(M, N, K):
     print((M, N, K), "exact-weight path", e16, "general path", e)
     tol = 1e-4 * max(1.0, (K / 768) ** 0.5)          # outputs are O(1); K = 64 has the largest weights (K^-1/2)
     assert e16 < tol and e < tol and e16 < 1.5 * e + 1e-5
+
+
+def test_exact_weight_gemm_is_bit_identical_across_block_tiles():
+    """The one-cross-term (fp16-exact weights) GEMM on every block-tile configuration: 128 x 128, 128 x 256, 256 x 256 -- same bits."""
+    from mlx8_ws_audio_transformer_amd import _lib, ops
+    x, w, b = _rand((2000, 768), 51), _rand((768, 768), 52, 768 ** -0.5).half().float(), _rand((768,), 53)
+    outs = {}
+    try:
+        for tile in (256, 128, 512):
+            _lib.tuning_set("gemm_tile", tile)
+            outs[tile] = ops.linear(x, w, b, "f16f8")
+    finally:
+        _lib.tuning_set("gemm_tile", 0)
+    assert torch.equal(outs[256], outs[128]) and torch.equal(outs[256], outs[512])
+    ref = x.double() @ w.double().t() + b.double()
+    assert (outs[256].double() - ref).abs().max().item() < 1e-4
