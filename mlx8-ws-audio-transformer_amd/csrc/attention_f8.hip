@@ -658,11 +658,14 @@ int launch_t(const Attn8Args& a, hipStream_t s) {
 
 int g_attn_shape = 0;
 void awt_attn_force_shape(int v) { g_attn_shape = v; }
+// must mirror the selection in launch_attention_f16f8: shapes 1 .. 5 and the training (lse) form keep P V's e4m3 cross terms
+bool attention_f16f8_reads_v8(bool with_lse) { return with_lse || (g_attn_shape >= 1 && g_attn_shape <= 5); }
 
 int launch_attention_f16f8(awt_ctx* c, const F8Planes& q, const F8Planes& k, const F8Planes& v, const F8Planes& o, float* o_f32,
                            float* lse, int B, int H, int S, hipStream_t s) {
   AWT_REQUIRE(B > 0 && H > 0 && S > 0, AWT_ERR_INVALID, "attention: bad shape");
   AWT_REQUIRE(q.p16 && q.hi8 && q.lo8 && k.p16 && k.hi8 && k.lo8 && v.p16 && v.hi8 && v.lo8, AWT_ERR_INVALID, "attention (f16f8): null plane");
+  // (v.hi8 / v.lo8 are only dereferenced by the forms attention_f16f8_reads_v8() names; the encoder does not fill them otherwise)
   AWT_REQUIRE(o_f32 || (o.p16 && o.lo8), AWT_ERR_INVALID, "attention (f16f8): null output plane (hi8 may be null: not consumed)");
   Attn8Args a{q.p16, k.p16, v.p16, q.hi8, q.lo8, k.hi8, k.lo8, v.hi8, v.lo8, o.p16, o.hi8, o.lo8, o_f32, lse, B, H, S};
   ProfScope prof(c, AWT_PROF_ATTENTION, s, 4.0 * (double)B * H * (double)S * S * 64);

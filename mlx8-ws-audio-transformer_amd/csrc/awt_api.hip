@@ -414,6 +414,7 @@ int encoder_layer(awt_encoder* e, Layer& L, const LayerBufs& b, int Bc, bool sav
   {
     GemmOut o{}; set_out(o, aqkv); o.scale = 0.125f * 1.4426950408889634f;   // head_dim^-1/2 and log2(e): see attention.hip
     o.S = S; o.H = H; o.plane_stride = plane;
+    o.skip_v8 = terms == PREC_F16F8 && !attention_f16f8_reads_v8(save);
     rc = linear_with_lora(e, b.u, b.ln1, d, L.qkv, L.lq, M, EPI_QKV, o, s); if (rc) return rc;
   }
   if (terms == PREC_F16F8) {

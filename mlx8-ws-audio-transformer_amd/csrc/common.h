@@ -279,6 +279,7 @@ struct GemmOut {
   int n_valid;                            // columns >= n_valid are not stored (N padded up to the tile)
   int S, H;                               // EPI_QKV: m = b * S + s ; plane stride = B*H*S*64
   int64_t plane_stride;
+  int skip_v8;                            // EPI_QKV, f16f8: do not write the e4m3 images of v (the single-product P V attention reads only its fp16 plane)
 };
 
 // `prec`: PREC_* of the operands (and of plane outputs)
@@ -324,6 +325,7 @@ int resample_prepare_impl(awt_ctx* c, int sr_in, int sr_out);
 void awt_free_tables(awt_ctx* c);
 void awt_attn_force_shape(int v);   // f16f8 attention workgroup shape: 0 auto, 1 / 2 / 3 (attention_f8.hip)
 void awt_gemm_set_gm(int v);       // row panels per tile group of the GEMM tile order (0 = default)
+bool attention_f16f8_reads_v8(bool with_lse);   // whether the f16f8 attention kernel that would be selected now stages the e4m3 images of v
 void awt_gemm_force_tile(int t);  // 0 auto, 64 / 128 / 256: tuning / tests (awt_tuning_set)
 
 // ---- backward-pass launchers

@@ -278,6 +278,7 @@ __device__ __forceinline__ void store_out8_f8(const GemmOut& o, int m, int n, fl
 #pragma unroll
   for (int t = 0; t < 8; ++t) { h[t] = f32_to_f16(v[t]); l[t] = (v[t] - f16_to_f32(h[t])) * (f8s * pow2f(kF8Lo)); v[t] *= f8s; }
   *reinterpret_cast<uint4*>(o.hi + off) = make_uint4(pack2(h[0], h[1]), pack2(h[2], h[3]), pack2(h[4], h[5]), pack2(h[6], h[7]));
+  if (EPI == EPI_QKV && o.skip_v8 && n >= 2 * o.H * 64) return;      // v: fp16 plane only
   if (o.hi8) *reinterpret_cast<uint2*>(o.hi8 + off) = make_uint2(fp8x4<0>(v[0], v[1], v[2], v[3]), fp8x4<0>(v[4], v[5], v[6], v[7]));   // null: see store_act4
   *reinterpret_cast<uint2*>(o.lo8 + off) = make_uint2(fp8x4<0>(l[0], l[1], l[2], l[3]), fp8x4<0>(l[4], l[5], l[6], l[7]));
 }

@@ -300,3 +300,22 @@ def test_fp16_exact_checkpoint_takes_the_one_cross_term_gemm_and_keeps_parity(na
     enc.load_state_dict({k: torch.from_numpy(v) for k, v in W.items()})                      # back to weights with non-zero lo planes
     again = enc(torch.from_numpy(mel).cuda()).last_hidden_state.cpu().numpy()
     assert np.array_equal(again, out_general)
+
+
+@pytest.mark.parametrize("shape", [0, 4, 1])
+def test_encoder_with_forced_attention_forms(shape):
+    """The QKV epilogue only writes v's e4m3 images when the attention form that will run reads them (the default single-product P V form does
+    not): forcing a cross-term form through the whole encoder must therefore still see valid planes."""
+    from mlx8_ws_audio_transformer_amd import _lib
+    cfg = wts.config("tiny", True)
+    W = wts.init_encoder_weights(cfg, 0, "test")
+    mel = _mel(cfg, 2)
+    ref = oracle_enc.encoder_forward(W, mel, cfg.heads, dtype=torch.float64).numpy()
+    _lib.tuning_set("attn_shape", shape)
+    try:
+        out = _native(cfg, "f16f8")(torch.from_numpy(mel).cuda()).last_hidden_state.cpu().numpy()
+    finally:
+        _lib.tuning_set("attn_shape", 0)
+    e = oracle_enc.error_norms(out, ref)
+    print(shape, e)
+    assert e["max_abs"] < 3e-4, e
