@@ -319,7 +319,7 @@ def sweep_main(a):
         print(json.dumps({
             "metric": "4s@16kHz clips/sec through mel+Whisper-%s encoder, %d-clip sweep" % (a.model, a.clips), "value": round(value, 2),
             "unit": "clips/s", "n_gpus": R.world, "steps": nb, "warmup": max(1, a.warmup), "ms_per_step": round(dt / nb * 1e3, 3),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic", "device": device_info(torch, dev),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": arithmetic_dtype(a.precision), "data": "synthetic", "device": device_info(torch, dev),
             "config": {"workload": "%d seeded piano-note clips (synth.py, seed 1234; distributions of AB/synthDataset.py:46-76) pre-staged as int16 in HBM, "
                                    "contiguous shard per rank, batches of %d incl. the tail batch -> log-mel -> Whisper-%s encoder -> hidden states" % (a.clips, a.batch, a.model),
                        "mode": "trimmed (NOT reference-equivalent)" if a.trimmed else "parity (clip zero-padded to 30 s, as the reference computes)",
@@ -376,6 +376,11 @@ class PowerSampler:
                 self.proc.wait(timeout=30)
         except Exception:
             pass
+
+
+def arithmetic_dtype(precision):
+    """The operand type of the MFMA products (accumulation, residual stream, softmax and LayerNorm statistics are fp32 in every mode)."""
+    return {"f16f8": "fp16", "fp16x3": "fp16", "bf16x3": "bf16", "bf16": "bf16"}.get(precision, "bf16")
 
 
 def bench_weights(cfg, kind):
@@ -502,7 +507,7 @@ def encode_main(a):
         "metric": "4s@16kHz clips/sec through mel+Whisper-%s encoder" % a.model,
         "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16", "data": "synthetic", "device": device_info(torch, dev),
+        "dtype": arithmetic_dtype(a.precision), "data": "synthetic", "device": device_info(torch, dev),
         "config": {"workload": "int16 PCM [B,64000] in HBM -> Whisper log-mel [B,80,%d] -> Whisper-%s encoder -> hidden [B,%d,%d] fp32"
                                % (cfg.n_frames, a.model, cfg.max_source_positions, cfg.d_model),
                    "mode": "trimmed (NOT reference-equivalent)" if a.trimmed else "parity (clip zero-padded to 30 s, as the reference computes)",
