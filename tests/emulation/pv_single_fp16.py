@@ -28,10 +28,10 @@ def forward(W, mel, heads, mode, qgain=1.0):
         q = (F.linear(y, W[p + "self_attn.q_proj.weight"], W[p + "self_attn.q_proj.bias"]) * hd ** -0.5 * qgain).view(B, S_, heads, hd).transpose(1, 2)
         k = F.linear(y, W[p + "self_attn.k_proj.weight"]).view(B, S_, heads, hd).transpose(1, 2)
         v = F.linear(y, W[p + "self_attn.v_proj.weight"], W[p + "self_attn.v_proj.bias"]).view(B, S_, heads, hd).transpose(1, 2)
-        s = q @ k.transpose(2, 3)
+        s = (f16(q) if mode == "q16" else q) @ k.transpose(2, 3)
         pu = torch.exp(s - s.amax(-1, keepdim=True))
         l = pu.sum(-1, keepdim=True)
-        if mode == "exact": att = (pu @ v) / l
+        if mode in ("exact", "q16"): att = (pu @ v) / l
         elif mode == "p16v16": att = (f16(pu) @ f16(v)) / l
         elif mode == "p16v16_lr": att = (f16(pu) @ f16(v)) / f16(pu).sum(-1, keepdim=True)
         elif mode == "p16": att = (f16(pu) @ v) / l
@@ -56,7 +56,7 @@ for profile, outl, qg in [("hf", False, 1.0), ("hf", False, 4.0), ("hf", False, 
     t = time.time()
     ref = forward(W, mel, cfg.heads, "exact", qg)
     line = f"{model} {profile} outl={outl} qgain={qg}: |ref|max {float(ref.abs().max()):.1f}"
-    for mode in ["p16v16", "p16v16_lr", "p16", "p16_vlo8", "pbf16"]:
+    for mode in ["p16v16", "q16", "p16", "pbf16"]:
         got = forward(W, mel, cfg.heads, mode, qg)
         line += f" | {mode} {float((got - ref).abs().max()):.2e}"
     print(line, f"({time.time() - t:.0f}s)", flush=True)
