@@ -522,7 +522,7 @@ extern "C" int awt_encoder_create(awt_ctx* c, const awt_encoder_cfg* cfg, awt_en
     if (!rc) rc = alloc_linear(e, &L.out, d, d);
     if (!rc) rc = alloc_linear(e, &L.fc1, f, d);
     if (!rc) rc = alloc_linear(e, &L.fc2, d, f);
-    if (e->prec == PREC_F16F8 && !cfg->training)       // four zero-initialised "not fp16-exact" flags per projection matrix (set_weight)
+    if ((e->prec == PREC_F16F8 || e->prec == PREC_F16X3) && !cfg->training)   // four zero-initialised "not fp16-exact" flags per projection matrix (set_weight)
       for (Linear* lin : {&L.qkv, &L.out, &L.fc1, &L.fc2}) if (!rc) rc = dev_alloc(e, (void**)&lin->w.d_inexact, 4 * sizeof(int));
     if (cfg->training) {
       if (!rc) rc = alloc_planes(e, &L.qkvT, d, 3 * d);
@@ -583,7 +583,7 @@ extern "C" int awt_encoder_set_weight(awt_encoder* e, const char* name, const fl
       const std::string key(p.key);
       if (rs == key + ".weight") {
         found = true; rc = check_shape(name, shape, rank, {p.N, p.K});
-        if (!rc && e->prec == PREC_F16F8 && !c.training && p.lin->w.d_inexact) {
+        if (!rc && (e->prec == PREC_F16F8 || e->prec == PREC_F16X3) && !c.training && p.lin->w.d_inexact) {
           // fp16-exact weights (checkpoints stored in half precision) let the GEMM drop one cross term: find out now, at upload time
           Planes& pl = p.lin->w;
           int* flag = pl.d_inexact + p.row_off / p.N;
@@ -727,7 +727,7 @@ extern "C" int awt_op_linear(awt_ctx* c, const float* x, const float* w, const f
   const Act ax = make_act(xh, xl, (size_t)M * K, terms);
   int rc = launch_split_planes(c, x, (int64_t)M * K, 1.0f, terms, kF8Act, xh, xl, ax.hi8, ax.lo8, s); if (rc) return rc;
   Planes pw; pw.hi = wh; pw.lo = wl; pw.x8 = (uint8_t*)wl + (size_t)N * K; pw.rows = N; pw.ld = K;
-  if (terms == PREC_F16F8) {   // as awt_encoder_set_weight does: fp16-exact weights take the one-cross-term GEMM; the flag is the
+  if (terms == PREC_F16F8 || terms == PREC_F16X3) {   // as awt_encoder_set_weight does: fp16-exact weights take the GEMM without the x_hi w_lo product; the flag is the
     int* flag = (int*)((char*)wl + align_up((size_t)N * K * 2));      // word of the workspace's 256-byte tail
     int host = 1;
     if (hipMemsetAsync(flag, 0, sizeof(int), s) != hipSuccess) return awt_fail(AWT_ERR_HIP, "op_linear: flag reset failed");

@@ -114,12 +114,13 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
       any_inexact |= (v != f16_to_f32(h));
     } else {
       bf16_t h, l; split16<PREC == PREC_F16X3>(v, h, l);
+      if (PREC == PREC_F16X3) any_inexact |= ((l & 0x7FFF) != 0);        // a non-zero lo element: the weight is not exactly fp16
       const int64_t o = w_frag_index(row_off + n, col_off + k, (int)(ld >> 5));
       hi[o] = h;
       if (lo) lo[o] = l;
     }
   }
-  if (PREC == PREC_F16F8 && inexact && __builtin_amdgcn_ballot_w64(any_inexact) != 0 && (threadIdx.x & 63) == 0) atomicOr(inexact, 1);
+  if ((PREC == PREC_F16F8 || PREC == PREC_F16X3) && inexact && __builtin_amdgcn_ballot_w64(any_inexact) != 0 && (threadIdx.x & 63) == 0) atomicOr(inexact, 1);
 }
 
 // ------------------------------------------------------------------------------------------------ conv1 im2col

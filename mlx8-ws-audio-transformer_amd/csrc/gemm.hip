@@ -56,7 +56,9 @@ template <int BK> __device__ __forceinline__ int swz(int row);
 template <> __device__ __forceinline__ int swz<64>(int row) { return (row >> 1) & 7; }
 template <> __device__ __forceinline__ int swz<32>(int row) { return (0x1320 >> (((row >> 2) & 3) * 4)) & 3; }  // {0,2,3,1}
 
-template <int TERMS, int BK, class CFG>
+// WX (TERMS == 3 only): the weights are exactly representable in the operand type, their lo plane is zero -- it is neither loaded nor multiplied
+// (two products per fragment pair: a_hi w + a_lo w).  Used for the split-fp16 mode on checkpoints released in half precision.
+template <int TERMS, int BK, class CFG, bool WX = false>
 struct Tile {
   static constexpr int BM = CFG::WM * CFG::TM * 16, BN = CFG::WN * CFG::TN * 16;
   static constexpr int THREADS = CFG::WM * CFG::WN * 64;
@@ -67,7 +69,8 @@ struct Tile {
   static constexpr int ITERS_A = (BM * CPR) / THREADS;      // LDS-DMA instructions per thread per plane
   static constexpr int KS = BK / 32;                        // MFMA k-steps per K-tile
   static constexpr int NA = NP * ITERS_A;                   // A DMA pieces per thread per K-tile
-  static constexpr int NB = NP * KS * CFG::TN;              // W fragment loads per lane per K-tile
+  static constexpr int NPW = WX ? 1 : NP;                   // planes of the W operand actually loaded
+  static constexpr int NB = NPW * KS * CFG::TN;             // W fragment loads per lane per K-tile
   static constexpr int LDS_BYTES = (2 * STAGE > CFG::WM * CFG::WN * 16 * 68 * 4) ? 2 * STAGE : CFG::WM * CFG::WN * 16 * 68 * 4;
 };
 
@@ -79,9 +82,9 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
 // Per-thread state of the operand streams.  The rows a thread copies are the same for every K-tile, so the (row-mapped)
 // A source pointers are computed once per K-segment and advanced by BK elements per K-tile; the W fragment pointer of
 // the lane (its n-tile row of fragment blocks) likewise.
-template <int TERMS, int BK, class CFG>
+template <int TERMS, int BK, class CFG, bool WX = false>
 struct Stager {
-  using T = Tile<TERMS, BK, CFG>;
+  using T = Tile<TERMS, BK, CFG, WX>;
   const bf16_t* a_hi[T::ITERS_A]; const bf16_t* a_lo[T::ITERS_A];
   const bf16_t* w_hi; const bf16_t* w_lo;     // lane's 16 bytes of fragment block (n-tile of the wave's first column tile, k-step w_k0)
   int64_t w_tile_stride;                       // elements between consecutive n-tiles = ksteps * 512
@@ -127,7 +130,7 @@ struct Stager {
     } else {
 #ifndef AWT_DIAG_NO_WLOAD
       constexpr int q = OP - T::NA;
-      constexpr int plane = q % T::NP, r = q / T::NP, j = r % CFG::TN, ks = r / CFG::TN;
+      constexpr int plane = q % T::NPW, r = q / T::NPW, j = r % CFG::TN, ks = r / CFG::TN;
       const int64_t off = (int64_t)j * w_tile_stride + (int64_t)(kk * T::KS + ks) * 512;
       if (plane == 0) nbh[ks][j] = *reinterpret_cast<const bf16x8*>(w_hi + off);
       else nbl[ks][j] = *reinterpret_cast<const bf16x8*>(w_lo + off);
@@ -283,10 +286,11 @@ __device__ __forceinline__ void store_out8_f8(const GemmOut& o, int m, int n, fl
   *reinterpret_cast<uint2*>(o.lo8 + off) = make_uint2(fp8x4<0>(l[0], l[1], l[2], l[3]), fp8x4<0>(l[4], l[5], l[6], l[7]));
 }
 
-template <int TERMS, int BK, int EPI, class CFG, bool F16>
+template <int TERMS, int BK, int EPI, class CFG, bool F16, bool WX = false>
 __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, 2) void gemm_kernel(GemmArgs g) {
-  using T = Tile<TERMS, BK, CFG>;
-  using ST = Stager<TERMS, BK, CFG>;
+  static_assert(!WX || TERMS == 3, "the exact-weight form belongs to the split product");
+  using T = Tile<TERMS, BK, CFG, WX>;
+  using ST = Stager<TERMS, BK, CFG, WX>;
   constexpr int TM = CFG::TM, TN = CFG::TN, KS = T::KS, STEPS = KS * TM, NOPS = T::NA + T::NB;
   constexpr int OPS_PER_STEP = (NOPS + STEPS - 1) / STEPS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -371,7 +375,7 @@ __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, 2) void gemm_kernel(GemmArg
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       if (TERMS == 3) {
-        acc[i][j] = mfma16<F16>(ah[s & 1], bl[ks][j], acc[i][j]);
+        if constexpr (!WX) acc[i][j] = mfma16<F16>(ah[s & 1], bl[ks][j], acc[i][j]);
         acc[i][j] = mfma16<F16>(al[s & 1], bh[ks][j], acc[i][j]);
       }
       acc[i][j] = mfma16<F16>(ah[s & 1], bh[ks][j], acc[i][j]);
@@ -386,7 +390,7 @@ __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, 2) void gemm_kernel(GemmArg
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) { bh[ks][j] = nbh[ks][j]; if (TERMS == 3) bl[ks][j] = nbl[ks][j]; }
+      for (int j = 0; j < TN; ++j) { bh[ks][j] = nbh[ks][j]; if (TERMS == 3 && !WX) bl[ks][j] = nbl[ks][j]; }
     load_a(cur, 0, 0, ah[0], al[0]);
     [&]<int... S>(std::integer_sequence<int, S...>) { (step(std::integral_constant<int, S>{}, cur, nxt, has_next), ...); }(std::make_integer_sequence<int, STEPS>{});
     if (has_next) st.advance(g, m0, n0, wc, wave, lane);
@@ -1041,14 +1045,14 @@ int g_force_tile = 0;  // 0 = auto, 64 / 128 / 256 = forced (tuning and tests)
 // panels, so row-panel groups are the default; AWT_GEMM_GROUP_N=n selects column groups for experiments.
 int g_group_n = 0;
 
-template <int TERMS, int BK, int EPI, class CFG, bool F16 = false>
+template <int TERMS, int BK, int EPI, class CFG, bool F16 = false, bool WX = false>
 int launch_one(GemmArgs a, hipStream_t s) {
-  using T = Tile<TERMS, BK, CFG>;
-  AWT_ONCE_PER_DEVICE(AWT_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_kernel<TERMS, BK, EPI, CFG, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES)));
+  using T = Tile<TERMS, BK, CFG, WX>;
+  AWT_ONCE_PER_DEVICE(AWT_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_kernel<TERMS, BK, EPI, CFG, F16, WX>, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES)));
   a.tiles_m = (a.M + T::BM - 1) / T::BM;
   a.tiles_n = (a.N + T::BN - 1) / T::BN;
   a.group_n = g_group_n; a.gm = g_gm;
-  hipLaunchKernelGGL((gemm_kernel<TERMS, BK, EPI, CFG, F16>), dim3(a.tiles_m * a.tiles_n), dim3(T::THREADS), T::LDS_BYTES, s, a);
+  hipLaunchKernelGGL((gemm_kernel<TERMS, BK, EPI, CFG, F16, WX>), dim3(a.tiles_m * a.tiles_n), dim3(T::THREADS), T::LDS_BYTES, s, a);
   AWT_HIP_CHECK(hipGetLastError());
   return AWT_OK;
 }
@@ -1087,6 +1091,11 @@ int launch_epi(GemmArgs a, int prec, hipStream_t s) {
     int tile = g_force_tile;
     if (!tile) tile = (a.N % 256 == 0 && t256h >= kSlots) ? 256 : (t128h >= kSlots ? 128 : 64);
     if (tile == 256 && a.N % 256 != 0) tile = 128;
+    if (a.nseg == 1 && a.seg[0].w_exact16) {     // fp16-exact weights: two products per fragment pair
+      if (tile == 256) return launch_one<3, 32, EPI, CfgW4, true, true>(a, s);
+      if (tile == 128) return launch_one<3, 32, EPI, Cfg128, true, true>(a, s);
+      return launch_one<3, 64, EPI, Cfg64, true, true>(a, s);
+    }
     if (tile == 256) return launch_one<3, 32, EPI, CfgW4, true>(a, s);
     if (tile == 128) return launch_one<3, 32, EPI, Cfg128, true>(a, s);
     return launch_one<3, 64, EPI, Cfg64, true>(a, s);

@@ -280,6 +280,20 @@ def test_default_precision_follows_the_checkpoint():
     assert explicit.precision == "f16f8"
 
 
+def test_fp16x3_mode_on_an_fp16_exact_checkpoint():
+    """The split-fp16 mode (what precision=None picks for outlier checkpoints) drops the zero a_hi w_lo product on fp16-exact weights too."""
+    cfg = wts.config("tiny", True)
+    W = wts.with_outlier_channels(wts.init_encoder_weights(cfg, 0, "test"), cfg, seed=0)
+    W16 = {k: (v.astype(np.float16).astype(np.float32) if v.ndim >= 2 else v) for k, v in W.items()}
+    mel = _mel(cfg, 2)
+    enc = _native(cfg, "fp16x3")
+    enc.load_state_dict({k: torch.from_numpy(v) for k, v in W16.items()})
+    out = enc(torch.from_numpy(mel).cuda()).last_hidden_state.cpu().numpy()
+    e = oracle_enc.error_norms(out, oracle_enc.encoder_forward(W16, mel, cfg.heads, dtype=torch.float64).numpy())
+    print(e)
+    assert e["rel_l2"] < OUTLIER_TOL["fp16x3"][0] and e["max_abs"] < OUTLIER_TOL["fp16x3"][1], e
+
+
 @pytest.mark.parametrize("name,trimmed,batch", [("tiny", True, 2), ("small", False, 1)])
 def test_fp16_exact_checkpoint_takes_the_one_cross_term_gemm_and_keeps_parity(name, trimmed, batch):
     """Checkpoints stored in half precision hold weights that are exactly fp16: their lo planes are zero, the library detects it when the

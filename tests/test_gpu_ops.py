@@ -176,3 +176,20 @@ def test_exact_weight_gemm_is_bit_identical_across_block_tiles():
     assert torch.equal(outs[256], outs[128]) and torch.equal(outs[256], outs[512])
     ref = x.double() @ w.double().t() + b.double()
     assert (outs[256].double() - ref).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("M,N,K", [(1500, 768, 768), (700, 384, 1536), (96, 2304, 768), (3000, 128, 3072)])
+def test_linear_fp16x3_with_fp16_exact_weights(M, N, K):
+    """Split-fp16 mode on weights that are exactly fp16: the a_hi w_lo product is zero and is not issued (two products per fragment pair).
+    The result stays at the mode's accuracy, for every block tile."""
+    from mlx8_ws_audio_transformer_amd import _lib, ops
+    x, w, b = _rand((M, K), 61), _rand((N, K), 62, K ** -0.5).half().float(), _rand((N,), 63)
+    ref = x.double() @ w.double().t() + b.double()
+    try:
+        for tile in (0, 64, 128, 256):
+            _lib.tuning_set("gemm_tile", tile)
+            y = ops.linear(x, w, b, "fp16x3")
+            err = (y.double() - ref).abs().max().item()
+            assert err < 1e-5 * max(1.0, (K / 768) ** 0.5), (tile, err)     # fp32 accumulation noise of O(1) outputs (bias included)
+    finally:
+        _lib.tuning_set("gemm_tile", 0)
