@@ -42,6 +42,9 @@ PEAK_BF16_DENSE_TFLOPS = 2500.0   # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.
 # operand + result bytes of the 50 GEMM launches of one step (Whisper-small, B = 64, two 2-byte operand planes, fp32 residual):
 # per layer qkv (295 + 885 MB), out (295 + 590), fc1 (295 + 1180), fc2 (1180 + 590) = 5.31 GB; conv stem 0.2 + 1.2 + 0.3 GB
 GEMM_ALGO_BYTES_PER_STEP = 12 * 5.31e9 + 1.7e9
+# the same with fp16-exact weights in the f16f8 format (3-byte operands: fp16 + lo8 activations, fp16 + hi8 weights; v without e4m3 images):
+# per layer qkv (221 + 5 + 737 MB), out (221 + 2 + 590), fc1 (221 + 7 + 885), fc2 (885 + 7 + 590) = 4.37 GB
+GEMM_ALGO_BYTES_PER_STEP_EXACT = 12 * 4.37e9 + 1.7e9
 ENCODER_GFLOP_PER_CLIP = {("small", False): 344.16, ("small", True): 36.30, ("tiny", False): 36.94, ("tiny", True): 3.33,
                           ("base", False): 87.37}
 PRECISIONS = ["f16f8", "fp16x3", "bf16x3", "bf16"]
@@ -533,7 +536,8 @@ def encode_main(a):
             if tj.get("build") == result["build"] and tj.get("precision") == a.precision:
                 result["roofline"]["traffic"] = round(tj["per_kernel"]["gemm_kernel"]["hbm_bytes_per_launch"])
                 result["roofline"]["traffic_note"] = "bytes per GEMM launch, FETCH_SIZE x2 (gfx950) + WRITE_SIZE, rocprofv3 --pmc passes on this build (profiles/traffic.json)"
-                result["roofline"]["algorithmic_bytes_per_launch"] = round(GEMM_ALGO_BYTES_PER_STEP / 50)
+                result["roofline"]["algorithmic_bytes_per_launch"] = round(
+                    (GEMM_ALGO_BYTES_PER_STEP_EXACT if (a.precision == "f16f8" and a.weights == "fp16") else GEMM_ALGO_BYTES_PER_STEP) / 50)
             else:
                 result["roofline"]["traffic_note"] = "profiles/traffic.json was measured on build %s (%s), this is %s: not attached" % (
                     tj.get("build"), tj.get("precision"), result["build"])
