@@ -65,11 +65,12 @@ def parse():
     ap.add_argument("--chunk", type=int, default=0, help="clips per kernel wave inside the library (0 = default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fast-mode", action="store_true")
-    ap.add_argument("--weights", default="fp16", choices=["fp16", "fp32"],
-                    help="random-init weights rounded to fp16-representable values, as published Whisper checkpoints are (they are stored in half "
-                         "precision; default), or left as arbitrary fp32 values.  The library detects fp16-exact weights at upload and its f16f8 "
-                         "GEMMs then drop the x_hi w_lo cross term, which is exactly zero (DESIGN.md 4.2b); the other case is reported beside it")
-    ap.add_argument("--no-power", action="store_true", help="do not start the rocm-smi sampler process (profiler runs: every child would be traced)")
+    ap.add_argument("--weights", default="fp32", choices=["fp16", "fp32"],
+                    help="fp32 (default, what SURVEY.md 8(d) specifies and what the reference's fully fp32-fine-tuned checkpoints hold): the seed-0 "
+                         "N(0, 0.02^2) initialisation as arbitrary fp32 values.  fp16: the same values rounded to fp16-representable ones (a frozen "
+                         "base released in half precision); the library detects that at upload and its f16f8 GEMMs drop the then-zero x_hi w_lo "
+                         "cross term (DESIGN.md 4.2b).  The other case is measured in the same run and reported beside the headline with its own roofline")
+    ap.add_argument("--no-power", action="store_true", help="do not sample package power / shader clock from sysfs")
     ap.add_argument("--cpu-clips", type=int, default=8)
     ap.add_argument("--workload", default="encode", choices=["encode", "sweep", "finetune", "noop"])
     ap.add_argument("--clips", type=int, default=10000, help="sweep workload: clips in the whole set (sharded over the ranks)")
@@ -92,12 +93,36 @@ def _free_port() -> int:
     return p
 
 
+def visible_gpus() -> int:
+    """GPUs this process could open, counted WITHOUT touching HIP or importing torch (the launcher parent must stay a process that has
+    never initialised the GPU): KFD topology nodes with SIMDs, capped by the DRM render nodes present and by HIP_VISIBLE_DEVICES /
+    ROCR_VISIBLE_DEVICES.  The rank processes check again with torch (Ranks.__init__), which is the authoritative answer."""
+    import glob
+    n = 0
+    for props in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            for line in open(props):
+                if line.startswith("simd_count") and int(line.split()[1]) > 0:
+                    n += 1
+        except OSError:
+            pass
+    render = len(glob.glob("/dev/dri/renderD*"))
+    if render:
+        n = min(n, render)
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def spawn_ranks(a) -> int:
-    """`python bench.py --gpus N` without a torchrun wrapper: start N fresh rank processes (one per GPU) BEFORE this process
-    touches the GPU, wait for them, and return the worst exit code.  Rank 0's stdout (the JSON line) is this process'."""
-    import torch          # device_count() does not initialise the GPU on this image
+    """`python bench.py --gpus N` without a torchrun wrapper: start N fresh rank processes (one per GPU), wait for them, and return the
+    worst exit code.  This parent imports neither torch nor anything that could initialise HIP (a GPU-initialised process must not start
+    other programs on this pool); the visible-GPU check here reads sysfs only and every rank repeats it with torch (exit 2).  Rank 0's
+    stdout (the JSON line) is this process'."""
     if a.dist_backend == "nccl" and a.workload != "noop":
-        have = torch.cuda.device_count()
+        have = visible_gpus()
         if have < a.gpus:
             print(f"bench.py: --gpus {a.gpus} but only {have} GPU(s) are visible", file=sys.stderr)
             return 2
@@ -108,19 +133,26 @@ def spawn_ranks(a) -> int:
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=e,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
-    worst = 0
-    deadline = time.time() + 3300
-    for p in procs:
-        try:
-            rc = p.wait(timeout=max(1.0, deadline - time.time()))
-        except subprocess.TimeoutExpired:
-            p.kill()
-            rc = 124
-        worst = worst or rc
-        if rc:                                   # a dead rank leaves the others in a collective: end them
-            for q in procs:
-                if q.poll() is None:
-                    q.kill()
+    # poll every rank: the first one to fail (or the deadline) ends the others -- a dead rank leaves the rest inside a collective
+    worst, deadline = 0, time.time() + 3300
+    live = list(procs)
+    while live:
+        for p in list(live):
+            rc = p.poll()
+            if rc is None:
+                continue
+            live.remove(p)
+            if rc and not worst:
+                worst = rc
+        if live and (worst or time.time() > deadline):
+            for q in live:
+                q.kill()
+            for q in live:
+                q.wait()
+            worst = worst or 124
+            break
+        if live:
+            time.sleep(0.05)
     return worst
 
 
@@ -139,6 +171,9 @@ class Ranks:
         self.backend = a.dist_backend if self.world > 1 else "none"
         self.dev = None
         if need_gpu:
+            if a.dist_backend == "nccl" and torch.cuda.device_count() < self.world:      # device_count() does not initialise the GPU on this image
+                print(f"bench.py: --gpus {self.world} but only {torch.cuda.device_count()} GPU(s) are visible", file=sys.stderr)
+                raise SystemExit(2)
             if not torch.cuda.is_available():
                 raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
             self.dev = torch.device("cuda", self.local_rank if a.dist_backend == "nccl" else 0)
@@ -334,22 +369,65 @@ def sweep_main(a):
     R.finish()
 
 
-class PowerSampler:
-    """rocm-smi in a helper process that is started BEFORE this process initialises the GPU (a GPU-initialised process must
-    not exec another program on this pool); `window()` runs untimed steps and returns the samples taken meanwhile."""
-
-    def __init__(self):
-        import tempfile
-        self.dir = tempfile.mkdtemp(prefix="awt_power_")
-        self.out, self.stop = os.path.join(self.dir, "samples.jsonl"), os.path.join(self.dir, "stop")
+def read_power_sysfs(root: str = "/sys/class/drm"):
+    """(package watts, shader clock MHz) of the busiest amdgpu card from sysfs: hwmon power1_average (microwatts; power1_input on
+    parts that only have that) and the starred line of pp_dpm_sclk.  None when no card exposes them.  Plain file reads: no rocm-smi,
+    no child process, nothing is exec'ed."""
+    import glob
+    best = None
+    for dev in glob.glob(os.path.join(root, "card*", "device")):
+        watts = None
+        for name in ("power1_average", "power1_input"):
+            for f in glob.glob(os.path.join(dev, "hwmon", "hwmon*", name)):
+                try:
+                    watts = int(open(f).read().strip()) / 1e6
+                except (OSError, ValueError):
+                    pass
+            if watts is not None:
+                break
+        if watts is None:
+            continue
+        mhz = None
         try:
-            self.proc = subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "power_sampler.py"), self.out, self.stop, str(os.getpid())],
-                                         stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        except Exception:
-            self.proc = None
+            for line in open(os.path.join(dev, "pp_dpm_sclk")):
+                if "*" in line:
+                    mhz = int("".join(ch for ch in line.split(":")[1] if ch.isdigit()))
+        except (OSError, ValueError, IndexError):
+            pass
+        if best is None or watts > best[0]:
+            best = (watts, mhz)
+    return best
+
+
+def profiler_attached() -> bool:
+    """rocprofv3 / roctracer preloads are in the environment: no helper of any kind is started under a profiler."""
+    return any(k in os.environ for k in ("ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD")) or \
+        any(k.startswith(("ROCPROFILER_", "ROCPROF_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+
+
+class PowerSampler:
+    """Package power and shader clock while the headline workload loops, read from sysfs by a THREAD of this process every 0.2 s
+    (round 2 ran rocm-smi -- a `#!/usr/bin/env python3` script -- from a helper process in a loop; under rocprofv3 that helper inherited
+    a GPU-initialised image and every launch was a refused exec).  `window()` runs untimed steps and returns the median of the samples
+    taken meanwhile; None when sysfs has no power file or a profiler is attached."""
+
+    def __init__(self, root: str = "/sys/class/drm", period: float = 0.2):
+        import threading
+        self.root, self.period = root, period
+        self.rows, self._stop = [], threading.Event()
+        self.thread = None
+        if not profiler_attached() and read_power_sysfs(root) is not None:
+            self.thread = threading.Thread(target=self._run, daemon=True)
+            self.thread.start()
+
+    def _run(self):
+        while not self._stop.wait(self.period):
+            r = read_power_sysfs(self.root)
+            if r is not None:
+                self.rows.append((time.time(), r[0], r[1]))
 
     def window(self, torch, step, dev, steps=60):
-        if self.proc is None:
+        if self.thread is None:
             return None
         torch.cuda.synchronize(dev)
         t0 = time.time()
@@ -357,28 +435,18 @@ class PowerSampler:
             step()
         torch.cuda.synchronize(dev)
         t1 = time.time()
-        time.sleep(0.3)
-        rows = []
-        try:
-            for line in open(self.out):
-                r = json.loads(line)
-                if t0 + 0.3 <= r["t"] <= t1:
-                    rows.append(r)
-        except Exception:
-            return None
+        rows = [r for r in list(self.rows) if t0 + 0.3 <= r[0] <= t1]
         if not rows:
             return None
         med = lambda v: sorted(v)[len(v) // 2]
-        return {"package_w": med([r["package_w"] for r in rows]), "sclk_mhz": med([r["sclk_mhz"] for r in rows]), "samples": len(rows),
-                "note": "median of rocm-smi samples taken by a helper process while %d untimed steps of the headline workload ran" % steps}
+        clocks = [r[2] for r in rows if r[2] is not None]
+        return {"package_w": round(med([r[1] for r in rows]), 1), "sclk_mhz": med(clocks) if clocks else None, "samples": len(rows),
+                "note": "median of sysfs samples (hwmon power1_average, pp_dpm_sclk) taken by a thread of this process while %d untimed steps of the headline workload ran" % steps}
 
     def close(self):
-        try:
-            open(self.stop, "w").close()
-            if self.proc is not None:
-                self.proc.wait(timeout=30)
-        except Exception:
-            pass
+        self._stop.set()
+        if self.thread is not None:
+            self.thread.join(timeout=2)
 
 
 def arithmetic_dtype(precision):
@@ -404,33 +472,44 @@ def load_bench_weights(torch, enc, W):
 
 def cpu_baseline_and_parity(a, torch, cfg, enc, pcm, pcm_host, out_first):
     """The oracle (CPU restatement of the reference path) on this host's cores: 1 warm-up + 3 timed passes over a bounded
-    sample, median, for mel alone, encoder alone and end to end; then HIP vs oracle on the same clips."""
+    sample, median, for mel alone, encoder alone and end to end -- once with every core this process may use
+    (north_star: "the node's own host cores (count stated)"; that is `value` / `cores`) and once with 16 threads (one GPU's share of the
+    host, round 2's figure, kept beside it); then HIP vs oracle on the same clips."""
     import numpy as np
     from mlx8_ws_audio_transformer_amd import synth, weights as wts
     from oracle import encoder as oenc, logmel as omel
     n = min(a.cpu_clips, pcm.shape[0])
     avail = len(os.sched_getaffinity(0))
-    cap = int(os.environ.get("AWT_CPU_THREADS", "16"))     # the GPU box gives one GPU's share of the host: 16 cores
-    ncpu = min(avail, cap)
-    torch.set_num_threads(ncpu)
     W = bench_weights(cfg, a.weights)
     clips_f32 = [synth.pcm_i16_to_f32(c) for c in pcm_host[:n]]
-    t_mel, t_enc = [], []
-    for it in range(4):                                     # pass 0 is the warm-up
-        t0 = time.perf_counter()
-        mel = omel.whisper_logmel(clips_f32, n_samples=cfg.n_frames * 160)
-        t1 = time.perf_counter()
-        with torch.no_grad():
-            ref = oenc.encoder_forward(W, mel, cfg.heads)
-        t2 = time.perf_counter()
-        if it:
-            t_mel.append(t1 - t0); t_enc.append(t2 - t1)
     med = lambda v: sorted(v)[len(v) // 2]
-    m_mel, m_enc, m_all = med(t_mel), med(t_enc), med([x + y for x, y in zip(t_mel, t_enc)])
-    base = {"value": round(n / m_all, 3), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d of the step's clips, fp32, parity mode; 1 warm-up + 3 timed passes, median (mel %.2f s + encoder %.2f s per pass)" % (n, m_mel, m_enc),
-            "threads_note": "torch threads = min(cores available to this process = %d, cap AWT_CPU_THREADS = %d)" % (avail, cap),
-            "mel_clips_per_s": round(n / m_mel, 3), "encoder_clips_per_s": round(n / m_enc, 3)}
+
+    def timed(threads, passes):
+        torch.set_num_threads(threads)
+        t_mel, t_enc, ref = [], [], None
+        for it in range(passes + 1):                        # pass 0 is the warm-up
+            t0 = time.perf_counter()
+            mel = omel.whisper_logmel(clips_f32, n_samples=cfg.n_frames * 160)
+            t1 = time.perf_counter()
+            with torch.no_grad():
+                ref = oenc.encoder_forward(W, mel, cfg.heads)
+            t2 = time.perf_counter()
+            if it:
+                t_mel.append(t1 - t0); t_enc.append(t2 - t1)
+        m_mel, m_enc, m_all = med(t_mel), med(t_enc), med([x + y for x, y in zip(t_mel, t_enc)])
+        return {"value": round(n / m_all, 3), "cores": torch.get_num_threads(), "mel_clips_per_s": round(n / m_mel, 3),
+                "encoder_clips_per_s": round(n / m_enc, 3), "mel_s": round(m_mel, 2), "encoder_s": round(m_enc, 2)}, mel, ref
+
+    cap = int(os.environ.get("AWT_CPU_THREADS", "0")) or avail       # AWT_CPU_THREADS caps the all-core leg (small CI hosts)
+    full, mel, ref = timed(min(avail, cap), 3)
+    base = {"value": full["value"], "unit": "clips/s", "cores": full["cores"], "kind": "port",
+            "sample": "%d of the step's clips, fp32, parity mode; 1 warm-up + 3 timed passes, median (mel %.2f s + encoder %.2f s per pass)" % (n, full["mel_s"], full["encoder_s"]),
+            "threads_note": "torch threads = every core available to this process (%d)" % avail,
+            "mel_clips_per_s": full["mel_clips_per_s"], "encoder_clips_per_s": full["encoder_clips_per_s"]}
+    if full["cores"] > 16:
+        t16, _, _ = timed(16, 2)
+        base["with_16_threads"] = {"value": t16["value"], "cores": t16["cores"], "mel_clips_per_s": t16["mel_clips_per_s"], "encoder_clips_per_s": t16["encoder_clips_per_s"],
+                                   "note": "the same sample on 16 threads (one GPU's share of the host: round 2's figure); 1 warm-up + 2 timed passes"}
     hid, feats = enc.encode_pcm(pcm[:n], return_features=True)
     e = oenc.error_norms(hid.cpu().numpy(), ref.numpy())
     parity = {"mel_max_abs": float(np.abs(feats.cpu().numpy() - mel).max()), "mel_tolerance": 1e-5,
@@ -464,8 +543,79 @@ def outlier_profile(a, torch, dev):
     return res
 
 
+def gemm_algorithmic_bytes_per_step(exact_frac: float) -> float:
+    """Operand + result bytes of one step's 50 GEMM launches (Whisper-small, B = 64): 3-byte operands for the projection matrices the library
+    found fp16-exact, 4-byte operands for the rest (linear in the exact fraction; the conv stem is the same in both)."""
+    return exact_frac * GEMM_ALGO_BYTES_PER_STEP_EXACT + (1.0 - exact_frac) * GEMM_ALGO_BYTES_PER_STEP
+
+
+def measure_encode(a, R, _lib, enc, pcm, kind):
+    """Warm-up, then EXACTLY a.steps timed passes of the hot path (barrier + synchronize on both sides, max over ranks) with the GEMM class
+    event-timed live on the launch stream, then one extra untimed pass for the other classes' shares.  Returns the block both weight cases
+    share: value, ms_per_step, roofline (with what the LIBRARY says about the weights, not what the command line asked for), time shares."""
+    B, world = pcm.shape[0], R.world
+    for _ in range(max(1, a.warmup)):
+        enc.encode_pcm(pcm)
+    R.sync()
+    _lib.prof_enable(True, ["gemm"])
+    for k in _lib.PROF_CLASSES:
+        _lib.prof_collect(k)
+    dt, mine, out = R.timed(lambda: enc.encode_pcm(pcm), a.steps)
+    prof = {"gemm": _lib.prof_collect("gemm")}
+    _lib.prof_enable(True, [k for k in _lib.PROF_CLASSES if k != "gemm"])
+    enc.encode_pcm(pcm)
+    for k in _lib.PROF_CLASSES:
+        if k != "gemm":
+            ms, n, fl = _lib.prof_collect(k)
+            prof[k] = (ms * a.steps, n, fl)      # scaled so the per-step division below applies to every class
+    _lib.prof_enable(False)
+    gemm_ms, gemm_n, gemm_flop = prof["gemm"]
+    achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    n_exact, n_mat = enc.exact16_matrices()
+    exact_frac = n_exact / max(1, n_mat)
+    terms = float(_lib.MFMA_PER_PAIR[enc.precision])
+    if enc.precision == "f16f8":
+        terms = 2.0 - 0.5 * exact_frac           # fp16 product + two e4m3 cross terms at twice the rate; an fp16-exact matrix drops one of them
+    elif enc.precision == "fp16x3":
+        terms = 3.0 - exact_frac
+    block = {
+        "value": round(B * world * a.steps / dt, 2), "unit": "clips/s", "ms_per_step": round(dt / a.steps * 1e3, 3),
+        "weights": ("seed-0 random init, N(0, 0.02^2) linears as arbitrary fp32 values (SURVEY.md 8(d); what a checkpoint fine-tuned in fp32 holds)" if kind == "fp32"
+                    else "the same initialisation rounded to fp16-representable values (a frozen base released in half precision)"),
+        "fp16_exact_projection_matrices": "%d of %d (found by the library at upload)" % (n_exact, n_mat),
+        "mfma_products_per_fragment_pair": round(terms, 3),
+        "roofline": {"bound": "mfma", "kernel": "gemm_f8_kernel / gemm_kernel<%s> (all encoder GEMMs: conv stem, QKV, out, fc1, fc2)" % enc.precision,
+                     "achieved": round(achieved, 2), "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(achieved / PEAK_BF16_DENSE_TFLOPS, 4), "traffic": None,
+                     "launches": gemm_n, "avg_launch_ms": round(gemm_ms / max(gemm_n, 1), 4),
+                     "mfma_issue_frac": round(terms * achieved / PEAK_BF16_DENSE_TFLOPS, 4)},
+        "time_share_ms_per_step": {k: round(v[0] / a.steps, 3) for k, v in prof.items()},
+    }
+    # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (tools/profile_round.sh); a committed summary is
+    # attached only when it was measured on THIS build (source hash), this precision and this kind of weights
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath) and a.model == "small" and not a.trimmed and B == 64:
+        try:
+            tj = json.load(open(tpath))
+            entries = tj.get("entries", [tj])
+            hit = [e for e in entries if e.get("build") == source_hash() and e.get("precision") == enc.precision and e.get("weights", "fp16") == kind]
+            if hit:
+                block["roofline"]["traffic"] = round(hit[-1]["per_kernel"]["gemm_kernel"]["hbm_bytes_per_launch"])
+                block["roofline"]["traffic_note"] = "bytes per GEMM launch, FETCH_SIZE x2 (gfx950) + WRITE_SIZE, rocprofv3 --pmc passes on this build (profiles/traffic.json)"
+                block["roofline"]["algorithmic_bytes_per_launch"] = round(gemm_algorithmic_bytes_per_step(exact_frac) / 50)
+            else:
+                block["roofline"]["traffic_note"] = "profiles/traffic.json has no entry for build %s / %s / %s weights: not attached" % (source_hash(), enc.precision, kind)
+        except Exception:
+            pass
+    gf = ENCODER_GFLOP_PER_CLIP.get((a.model, a.trimmed))
+    if gf:
+        block["end_to_end_algorithmic_tflops"] = round(block["value"] * gf / 1e3, 2)
+        block["end_to_end_frac_of_mfma_peak"] = round(block["value"] * gf / 1e3 / PEAK_BF16_DENSE_TFLOPS / world, 4)
+    return block, dt, mine, out
+
+
 def encode_main(a):
-    sampler = PowerSampler() if (int(os.environ.get("RANK", "0")) == 0 and a.gpus == 1 and not a.no_power) else None   # before the GPU is initialised
+    sampler = PowerSampler() if (int(os.environ.get("RANK", "0")) == 0 and a.gpus == 1 and not a.no_power) else None   # a sysfs-reading thread; never under a profiler
     R = Ranks(a)
     torch, dev, rank, world = R.torch, R.dev, R.rank, R.world
     from mlx8_ws_audio_transformer_amd import _lib, synth, weights as wts
@@ -476,90 +626,51 @@ def encode_main(a):
     # synthetic clips: this rank's contiguous shard of the seeded piano-note set
     pcm_host = synth.synth_clips_i16(B, seed=1234, first=rank * B)
     pcm = torch.from_numpy(pcm_host).to(dev)
-    enc = load_bench_weights(torch, NativeWhisperEncoder(cfg, precision=a.precision, device=str(dev), chunk_clips=a.chunk, seed=0, init_profile="hf").eval(),
-                             bench_weights(cfg, a.weights))
 
-    for _ in range(a.warmup):
-        enc.encode_pcm(pcm)
-    torch.cuda.synchronize(dev)
+    def build(kind, precision=a.precision):
+        return load_bench_weights(torch, NativeWhisperEncoder(cfg, precision=precision, device=str(dev), chunk_clips=a.chunk, seed=0, init_profile="hf").eval(),
+                                  bench_weights(cfg, kind))
 
-    # ---- timed region: the dominant kernel class (GEMM) is event-timed live inside it, on the launch stream
-    _lib.prof_enable(True, ["gemm"])
-    for k in _lib.PROF_CLASSES:
-        _lib.prof_collect(k)
-    dt, mine, out = R.timed(lambda: enc.encode_pcm(pcm), a.steps)
-    prof = {"gemm": _lib.prof_collect("gemm")}
-    # the other classes' time shares come from one extra, untimed step
-    _lib.prof_enable(True, [k for k in _lib.PROF_CLASSES if k != "gemm"])
-    enc.encode_pcm(pcm)
-    for k in _lib.PROF_CLASSES:
-        if k != "gemm":
-            ms, n, fl = _lib.prof_collect(k)
-            prof[k] = (ms * a.steps, n, fl)      # scaled so the per-step division below applies to every class
-    _lib.prof_enable(False)
+    enc = build(a.weights)
+    head, dt, mine, out = measure_encode(a, R, _lib, enc, pcm, a.weights)
     rates = R.gather(B * a.steps / mine)
-
-    clips = B * world * a.steps
-    value = clips / dt
-    gemm_ms, gemm_n, gemm_flop = prof["gemm"]
-    achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-    terms = _lib.MFMA_PER_PAIR[a.precision]
-    if a.precision == "f16f8" and a.weights == "fp16":
-        terms = 1.5        # fp16-exact weights: fp16 product + ONE e4m3 cross term at twice the rate (the conv stem's two small GEMMs keep both)
     result = {
         "metric": "4s@16kHz clips/sec through mel+Whisper-%s encoder" % a.model,
-        "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "value": head["value"], "unit": "clips/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": arithmetic_dtype(a.precision), "data": "synthetic", "device": device_info(torch, dev),
         "config": {"workload": "int16 PCM [B,64000] in HBM -> Whisper log-mel [B,80,%d] -> Whisper-%s encoder -> hidden [B,%d,%d] fp32"
                                % (cfg.n_frames, a.model, cfg.max_source_positions, cfg.d_model),
                    "mode": "trimmed (NOT reference-equivalent)" if a.trimmed else "parity (clip zero-padded to 30 s, as the reference computes)",
                    "clips_per_gpu_per_step": B, "precision": a.precision,
-                   "mfma_products_per_fragment_pair": terms, "weights": ("random-init Whisper-%s shape, seed 0, rounded to fp16-representable values as checkpoints released in half precision are "
-                                                                             "(the f16f8 GEMMs drop the then-zero x_hi w_lo cross term; `general_fp32_weights` is the other case)" % a.model)
-                   if a.weights == "fp16" else "random-init Whisper-%s shape, seed 0, arbitrary fp32 values" % a.model,
+                   "mfma_products_per_fragment_pair": head["mfma_products_per_fragment_pair"], "weights": head["weights"],
+                   "fp16_exact_projection_matrices": head["fp16_exact_projection_matrices"],
                    "parallelism": "dp%d (clip shards, no data-path collective)" % world},
-        "roofline": {"bound": "mfma", "kernel": "gemm_kernel<%s> (all encoder GEMMs: conv stem, QKV, out, fc1, fc2)" % a.precision,
-                     "achieved": round(achieved, 2), "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / PEAK_BF16_DENSE_TFLOPS, 4), "traffic": None,
-                     "launches": gemm_n, "avg_launch_ms": round(gemm_ms / max(gemm_n, 1), 4),
-                     "mfma_issue_frac": round(terms * achieved / PEAK_BF16_DENSE_TFLOPS, 4)},
-        "time_share_ms_per_step": {k: round(v[0] / a.steps, 3) for k, v in prof.items()},
+        "roofline": head["roofline"], "time_share_ms_per_step": head["time_share_ms_per_step"],
         "ranks": R.describe(rates), "build": source_hash(),
     }
-    # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (tools/profile_round.sh); the committed
-    # summary is attached only when it was measured on THIS build (source hash) and this workload
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath) and a.model == "small" and not a.trimmed and B == 64:
-        try:
-            tj = json.load(open(tpath))
-            if tj.get("build") == result["build"] and tj.get("precision") == a.precision:
-                result["roofline"]["traffic"] = round(tj["per_kernel"]["gemm_kernel"]["hbm_bytes_per_launch"])
-                result["roofline"]["traffic_note"] = "bytes per GEMM launch, FETCH_SIZE x2 (gfx950) + WRITE_SIZE, rocprofv3 --pmc passes on this build (profiles/traffic.json)"
-                result["roofline"]["algorithmic_bytes_per_launch"] = round(
-                    (GEMM_ALGO_BYTES_PER_STEP_EXACT if (a.precision == "f16f8" and a.weights == "fp16") else GEMM_ALGO_BYTES_PER_STEP) / 50)
-            else:
-                result["roofline"]["traffic_note"] = "profiles/traffic.json was measured on build %s (%s), this is %s: not attached" % (
-                    tj.get("build"), tj.get("precision"), result["build"])
-        except Exception:
-            pass
-    gf = ENCODER_GFLOP_PER_CLIP.get((a.model, a.trimmed))
-    if gf:
-        result["end_to_end_algorithmic_tflops"] = round(value * gf / 1e3, 2)
-        result["end_to_end_frac_of_mfma_peak"] = round(value * gf / 1e3 / PEAK_BF16_DENSE_TFLOPS / world, 4)
+    for k in ("end_to_end_algorithmic_tflops", "end_to_end_frac_of_mfma_peak"):
+        if k in head:
+            result[k] = head[k]
 
     if rank == 0 and world == 1:
-        # ---- package power and shader clock while the headline workload runs (rocm-smi in a child process, outside the timed
+        # ---- package power and shader clock while the headline workload runs (sysfs samples on a thread of this process, outside the timed
         #      region): the encoder sits at the package power limit, which is what caps roofline.frac
         result["power"] = sampler.window(torch, lambda: enc.encode_pcm(pcm), dev) if sampler else None
-        # ---- the other operand modes, reported beside the headline with all three error norms vs the headline's output
         if not a.no_fast_mode:
+            # ---- the other kind of weights, same build and mode, as a first-class block with its own roofline
+            if a.precision in ("f16f8", "fp16x3"):
+                okind = "fp16" if a.weights == "fp32" else "fp32"
+                other = build(okind)
+                oblock, _, _, _ = measure_encode(a, R, _lib, other, pcm, okind)
+                result["fp16_exact_weights" if okind == "fp16" else "general_fp32_weights"] = oblock
+                del other
+            # ---- the other operand modes, reported beside the headline with all three error norms vs the headline's output
             side = {}
             for prec in PRECISIONS:
                 if prec == a.precision:
                     continue
-                other = load_bench_weights(torch, NativeWhisperEncoder(cfg, precision=prec, device=str(dev), chunk_clips=a.chunk, seed=0, init_profile="hf").eval(),
-                                           bench_weights(cfg, a.weights))
+                other = build(a.weights, prec)
                 for _ in range(max(1, a.warmup)):
                     other.encode_pcm(pcm)
                 fdt, _, fout = R.timed(lambda: other.encode_pcm(pcm), a.steps)
@@ -570,15 +681,6 @@ def encode_main(a):
                               "mfma_products_per_fragment_pair": _lib.MFMA_PER_PAIR[prec]}
                 del other
             result["other_precisions"] = side
-            if a.weights == "fp16" and a.precision == "f16f8":
-                # the same mode on weights that are NOT fp16-exact: the general two-cross-term GEMM
-                gen = NativeWhisperEncoder(cfg, precision=a.precision, device=str(dev), chunk_clips=a.chunk, seed=0, init_profile="hf").eval()
-                for _ in range(max(1, a.warmup)):
-                    gen.encode_pcm(pcm)
-                gdt, _, _ = R.timed(lambda: gen.encode_pcm(pcm), a.steps)
-                result["general_fp32_weights"] = {"value": round(B * a.steps / gdt, 2), "unit": "clips/s", "ms_per_step": round(gdt / a.steps * 1e3, 3),
-                                                  "note": "same build and mode, random-init weights left as arbitrary fp32 values: both cross terms of every GEMM"}
-                del gen
         # ---- CPU baseline: the oracle (CPU restatement of the reference path) on this host's cores, bounded sample
         if not a.no_cpu_baseline:
             result["cpu_baseline"], result["parity"], _ = cpu_baseline_and_parity(a, torch, cfg, enc, pcm, pcm_host, out)

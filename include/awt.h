@@ -143,6 +143,12 @@ void awt_encoder_destroy(awt_encoder* e);
 int awt_encoder_set_weight(awt_encoder* e, const char* hf_name, const float* data, const int64_t* shape, int rank,
                            void* stream);
 
+/* How many of the encoder's projection matrices (per layer: the fused q|k|v block, out_proj, fc1, fc2) hold only fp16-representable values
+ * -- i.e. run the exact-weight GEMM form with one cross term fewer -- and how many such matrices there are.  Measured at upload time
+ * (awt_encoder_set_weight); bench.py derives its MFMA products per fragment pair and algorithmic bytes from this, not from a flag.
+ * n_exact = 0 in the modes that never look (bf16, bf16x3, training). */
+int awt_encoder_exact16_matrices(const awt_encoder* e, int* n_exact, int* n_total);
+
 size_t awt_encoder_workspace_bytes(const awt_encoder* e, int B);
 
 /* input_features float32 [B, n_mels, 2*n_ctx] -> last_hidden_state float32 [B, n_ctx, d_model].
@@ -258,7 +264,9 @@ int awt_op_layernorm_param_grad(awt_ctx* c, const float* dy, const float* x, flo
                                 void* workspace, size_t ws_bytes, void* stream);
 int awt_op_column_sums(awt_ctx* c, const float* a, float* sums, int M, int d, void* workspace, size_t ws_bytes, void* stream);
 /* CrossEntropyLoss(ignore_index = -100, mean) over the first `vocab` of `ld` columns: *loss and d(loss)/d(logits) [M, ld]
- * (padding columns zero).  scratch: (M + 1) * 4 bytes.                    HF:modeling_whisper.py:1079-1086 */
+ * (padding columns zero).  scratch: (M + 1) * 4 bytes.                    HF:modeling_whisper.py:1079-1086
+ * Only -100 is ignored.  Any other target outside [0, vocab) -- torch raises for it -- makes *loss NaN (the call itself cannot fail
+ * without a synchronisation); the Python wrapper validates the labels on the host side and raises before launching. */
 int awt_op_cross_entropy(awt_ctx* c, const float* logits, const int64_t* labels, int M, int vocab, int ld, float* loss, float* dlogits,
                          void* scratch, void* stream);
 /* softmax(0.125 q k^T [+ causal mask]) v for head_dim 64 with few query rows.  Row (b, i) of q at q + (b Lq + i) ldq + 64 h; row

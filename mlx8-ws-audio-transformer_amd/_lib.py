@@ -54,6 +54,7 @@ _SIGNATURES = {
     "awt_encoder_create": (_i, [_vp, C.POINTER(EncoderCfg), C.POINTER(_vp)]),
     "awt_encoder_destroy": (None, [_vp]),
     "awt_encoder_set_weight": (_i, [_vp, C.c_char_p, _vp, C.POINTER(_i64), _i, _vp]),
+    "awt_encoder_exact16_matrices": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
     "awt_encoder_workspace_bytes": (_sz, [_vp, _i]),
     "awt_encoder_forward": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "awt_encoder_train_workspace_bytes": (_sz, [_vp, _i]),

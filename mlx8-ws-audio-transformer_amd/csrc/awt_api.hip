@@ -638,6 +638,15 @@ static int require_weights(const awt_encoder* e) {
   return AWT_OK;
 }
 
+extern "C" int awt_encoder_exact16_matrices(const awt_encoder* e, int* n_exact, int* n_total) {
+  AWT_REQUIRE(e && n_exact && n_total, AWT_ERR_INVALID, "encoder_exact16_matrices: null argument");
+  int ex = 0, tot = 0;
+  for (const Layer& L : e->layers)
+    for (const Linear* lin : {&L.qkv, &L.out, &L.fc1, &L.fc2}) { ++tot; if (lin->w.exact16) ++ex; }
+  *n_exact = ex; *n_total = tot;
+  return AWT_OK;
+}
+
 extern "C" size_t awt_encoder_workspace_bytes(const awt_encoder* e, int B) {
   if (!e || B <= 0) return 0;
   return carve(e, nullptr, std::min(B, e->chunk)).bytes;
@@ -714,6 +723,9 @@ extern "C" int awt_op_linear(awt_ctx* c, const float* x, const float* w, const f
   bf16_t* wh = (bf16_t*)base;                 base += align_up((size_t)N * K * 2);
   bf16_t* wl = (bf16_t*)base;
   if (terms == PREC_F16F6) {   // experimental: fp16 plane + two e3m2 planes (the second 2-byte plane's space holds both, 0.75 B per element each)
+#ifndef AWT_EXPERIMENTAL_F6
+    return awt_fail(AWT_ERR_INVALID, "op_linear (f16f6): the FP6 cross-term experiment is not part of this build (compile with -DAWT_EXPERIMENTAL_F6)");
+#else
     AWT_REQUIRE(N % 256 == 0, AWT_ERR_INVALID, "op_linear (f16f6): N % 256 == 0 required");
     Act ax6; ax6.p16 = xh; ax6.hi8 = (uint8_t*)xl; ax6.lo8 = (uint8_t*)xl + (size_t)M * K / 4 * 3;
     uint8_t* w6 = (uint8_t*)wl; uint8_t* wl6 = w6 + (size_t)N * K / 4 * 3;
@@ -723,6 +735,7 @@ extern "C" int awt_op_linear(awt_ctx* c, const float* x, const float* w, const f
     GemmSeg sg6 = seg_plain(ax6, K, pw6, 0, K, M);
     GemmOut o6{}; o6.f32 = y; o6.ldo = N; o6.bias = bias; o6.n_valid = N;
     return launch_gemm(c, M, N, &sg6, 1, terms, EPI_F32, o6, s);
+#endif
   }
   const Act ax = make_act(xh, xl, (size_t)M * K, terms);
   int rc = launch_split_planes(c, x, (int64_t)M * K, 1.0f, terms, kF8Act, xh, xl, ax.hi8, ax.lo8, s); if (rc) return rc;

@@ -153,7 +153,8 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logit
   const float* z = logits + (int64_t)m * ld;
   float* g = dlogits + (int64_t)m * ld;
   const int64_t lab = labels[m];
-  const bool ignored = lab < 0 || lab >= vocab;
+  const bool ignored = lab == -100;                                  // the ONLY ignored value (torch.nn.CrossEntropyLoss(ignore_index=-100))
+  const bool invalid = !ignored && (lab < 0 || lab >= vocab);        // torch raises for such a target; here the row's loss becomes NaN (never silent)
   float mx = -3.0e38f;
   for (int i = tid; i < vocab; i += 256) mx = fmaxf(mx, z[i]);
 #pragma unroll
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logit
   const float lse = mx + __logf(sum);
   const int n = *count;
   const float scale = (ignored || n <= 0) ? 0.f : 1.0f / (float)n;
-  if (tid == 0) row_loss[m] = ignored ? 0.f : lse - z[lab];
+  if (tid == 0) row_loss[m] = ignored ? 0.f : (invalid ? __builtin_nanf("") : lse - z[lab]);
   const float inv = 1.0f / sum;
   for (int i = tid; i < ld; i += 256) {
     float v = 0.f;
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logit
 }
 __global__ void count_labels_kernel(const int64_t* labels, int M, int vocab, int* count) {
   int n = 0;
-  for (int i = threadIdx.x; i < M; i += 64) n += (labels[i] >= 0 && labels[i] < vocab) ? 1 : 0;
+  for (int i = threadIdx.x; i < M; i += 64) n += labels[i] != -100 ? 1 : 0;       // out-of-range targets count: their rows poison the loss with NaN (ce_kernel)
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o);
   if (threadIdx.x == 0) *count = n;

@@ -341,6 +341,7 @@ __global__ __launch_bounds__(256) void outer_reduce_final_kernel(const float* __
 }
 
 
+#ifdef AWT_EXPERIMENTAL_F6
 // ------------------------------------------------------------------------------------------------ PREC_F16F6 operand images (experimental)
 // One thread per (row, group of 32 consecutive k): fp16 plane + the two e3m2 planes.  WEIGHT: fragment-major images, exponent kF6Wgt.
 template <bool WEIGHT>
@@ -380,6 +381,7 @@ __global__ __launch_bounds__(256) void planes_f6_kernel(const float* __restrict_
     *reinterpret_cast<uint2*>(dl + 8 * i) = make_uint2(ql[2 * i], ql[2 * i + 1]);
   }
 }
+#endif  // AWT_EXPERIMENTAL_F6
 }  // namespace
 
 int launch_layernorm(awt_ctx* c, const float* x, const float* gamma, const float* beta, int M, int d, float eps,
@@ -508,6 +510,7 @@ int launch_outer_reduce(awt_ctx* c, const bf16_t* x_hi, const bf16_t* x_lo, int6
   return AWT_OK;
 }
 
+#ifdef AWT_EXPERIMENTAL_F6
 int launch_split_planes_f6(awt_ctx* c, const float* x, int M, int K, bf16_t* p16, uint8_t* hi6, uint8_t* lo6, hipStream_t s) {
   AWT_REQUIRE(x && p16 && hi6 && lo6 && M > 0 && K > 0 && K % 64 == 0, AWT_ERR_INVALID, "split_planes_f6: K must be a multiple of 64");
   const int64_t n = (int64_t)M * (K / 32);
@@ -522,3 +525,4 @@ int launch_pack_weight_f6(awt_ctx* c, const float* w, int N, int K, bf16_t* w16,
   AWT_HIP_CHECK(hipGetLastError());
   return AWT_OK;
 }
+#endif  // AWT_EXPERIMENTAL_F6

@@ -33,6 +33,9 @@
 
 namespace {
 
+#ifndef AWT_GEMM_WDEC
+#define AWT_GEMM_WDEC 1   // f16f8 kernel: the K-tile barrier waits for the LDS-DMA only; W fragment loads are waited for at their consumers
+#endif
 int g_gm = AWT_GEMM_GM;   // row panels per tile group (awt_tuning_set "gemm_gm")
 constexpr int kMaxSeg = 3;
 typedef int i32x4_t __attribute__((ext_vector_type(4)));
@@ -146,10 +149,10 @@ struct Stager {
 // a 16-byte fp32 / 8-byte bf16 piece of a row and 16 lanes cover 64 contiguous columns).  Side inputs (residual row,
 // positional table, saved pre-activation) are loaded by load_side4 one strip AHEAD of their use: in the epilogue every
 // wave of the workgroup is past its last MFMA, so a load-then-use per strip would expose its latency eight times.
-template <int EPI>
+template <int EPI, bool FULL = false>
 __device__ __forceinline__ float4 load_side4(const GemmOut& o, int m, int n, int M) {
   float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (m >= M || n >= o.n_valid) return r;
+  if constexpr (!FULL) { if (m >= M || n >= o.n_valid) return r; }
   if (EPI == EPI_F32_RESID) {
     r = *reinterpret_cast<const float4*>(o.resid + (int64_t)m * o.ldo + n);
   } else if (EPI == EPI_F32_GELU_POS) {
@@ -168,18 +171,16 @@ __device__ __forceinline__ float4 load_side4(const GemmOut& o, int m, int n, int
 }
 
 // OP = precision of plane outputs (PREC_BF16X3: bf16 hi / lo; PREC_F16X3: fp16 hi / lo; PREC_F16F8: fp16 + two e4m3 planes)
-template <int EPI, int OP>
-__device__ __forceinline__ void store_out4(const GemmOut& o, int m, int n, float4 acc, float4 side, int M) {
+// FULL / b: as store_out8_f8 below (no per-row predicate inside a full tile; the lane's bias values are loaded once per tile)
+template <int EPI, int OP, bool FULL>
+__device__ __forceinline__ void store_out4(const GemmOut& o, int m, int n, float4 acc, float4 side, float4 b, int M) {
 #ifdef AWT_DIAG_NO_STORE   // timing-only: epilogue arithmetic kept alive, nothing written
   if (acc.x != 123.456f) { asm volatile("" ::"v"(acc.y), "v"(side.x)); return; }
 #endif
-  if (m >= M || n >= o.n_valid) return;
+  if constexpr (!FULL) { if (m >= M || n >= o.n_valid) return; }
   float v[4] = {acc.x, acc.y, acc.z, acc.w};
   const float sd[4] = {side.x, side.y, side.z, side.w};
-  if (o.bias) {
-    const float4 b = *reinterpret_cast<const float4*>(o.bias + n);
-    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-  }
+  v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
   if (EPI == EPI_F32 || EPI == EPI_F32_RESID || EPI == EPI_F32_GELU_POS) {
     float* dst = o.f32 + (int64_t)m * o.ldo + n;
     if (EPI == EPI_F32_RESID) {
@@ -241,18 +242,21 @@ __device__ __forceinline__ void store_out4(const GemmOut& o, int m, int n, float
 // Eight consecutive columns of one row in the f16f8 output format: 16-byte fp16 and 8-byte e4m3 stores (the 4-column form
 // writes 4-byte pieces of the e4m3 planes: twice the store instructions for the same bytes).  n is a multiple of 8, so the
 // eight columns never straddle a head or a q / k / v boundary of EPI_QKV.
-template <int EPI>
-__device__ __forceinline__ void store_out8_f8(const GemmOut& o, int m, int n, float4 acc0, float4 acc1, float4 side0, float4 side1, int M) {
+// FULL: the tile lies inside [0, M) x [0, n_valid) (decided once per workgroup): no per-row predicate, hence no branch between the stores of a strip --
+// with one, hipcc opened every row group with s_waitcnt vmcnt(0), i.e. waited for the previous group's stores to be acknowledged, 16 times per tile.
+// b0 / b1: the lane's eight bias values, loaded once per tile (its columns are the same in every strip).
+template <int EPI, bool FULL>
+__device__ __forceinline__ void store_out8_f8(const GemmOut& o, int m, int n, float4 acc0, float4 acc1, float4 side0, float4 side1, float4 b0, float4 b1, int M) {
   static_assert(EPI != EPI_BF16_GELU_SAVE && EPI != EPI_BF16_DGELU, "training epilogues have no f16f8 form");
-  if (m >= M || n >= o.n_valid) return;
+  if constexpr (!FULL) { if (m >= M || n >= o.n_valid) return; }
   float v[8] = {acc0.x, acc0.y, acc0.z, acc0.w, acc1.x, acc1.y, acc1.z, acc1.w};
   const float sd[8] = {side0.x, side0.y, side0.z, side0.w, side1.x, side1.y, side1.z, side1.w};
-  if (o.bias) {
-    const float4 b0 = *reinterpret_cast<const float4*>(o.bias + n), b1 = *reinterpret_cast<const float4*>(o.bias + n + 4);
-    v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-  }
+  v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
   if (EPI == EPI_F32 || EPI == EPI_F32_RESID || EPI == EPI_F32_GELU_POS) {
     float* dst = o.f32 + (int64_t)m * o.ldo + n;
+#ifdef AWT_DIAG_NO_STORE
+    dst = o.f32 + (threadIdx.x & 63) * 8;
+#endif
 #pragma unroll
     for (int t = 0; t < 8; ++t) v[t] = EPI == EPI_F32_RESID ? v[t] + sd[t] : (EPI == EPI_F32_GELU_POS ? gelu_erf(v[t]) + sd[t] : v[t]);
     *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
@@ -280,6 +284,9 @@ __device__ __forceinline__ void store_out8_f8(const GemmOut& o, int m, int n, fl
   bf16_t h[8]; float l[8];
 #pragma unroll
   for (int t = 0; t < 8; ++t) { h[t] = f32_to_f16(v[t]); l[t] = (v[t] - f16_to_f32(h[t])) * (f8s * pow2f(kF8Lo)); v[t] *= f8s; }
+#ifdef AWT_DIAG_NO_STORE   // timing-only: every store instruction stays, but all waves write the same 1 KB per plane (L2-resident: no HBM write traffic)
+  off = (threadIdx.x & 63) * 8;
+#endif
   *reinterpret_cast<uint4*>(o.hi + off) = make_uint4(pack2(h[0], h[1]), pack2(h[2], h[3]), pack2(h[4], h[5]), pack2(h[6], h[7]));
   if (EPI == EPI_QKV && o.skip_v8 && n >= 2 * o.H * 64) return;      // v: fp16 plane only
   if (o.hi8) *reinterpret_cast<uint2*>(o.hi8 + off) = make_uint2(fp8x4<0>(v[0], v[1], v[2], v[3]), fp8x4<0>(v[4], v[5], v[6], v[7]));   // null: see store_act4
@@ -407,32 +414,39 @@ __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, 2) void gemm_kernel(GemmArg
   constexpr int PITCH = 68;  // floats; 16 x 68 x 4 B = 4352 B per wave
   float* patch = reinterpret_cast<float*>(smem) + wave * (16 * PITCH);
   const int em0 = m0 + wr * TM * 16, en = n0 + wc * 64 + frow * 4;
-  float4 side[4], side_next[4];
+  float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (g.out.bias && en < g.out.n_valid) bias4 = *reinterpret_cast<const float4*>(g.out.bias + en);
+  auto strips = [&](auto full_t) {
+    constexpr bool FULL = decltype(full_t)::value;
+    float4 side[4], side_next[4];
 #pragma unroll
-  for (int it = 0; it < 4; ++it) side[it] = load_side4<EPI>(g.out, em0 + fq + 4 * it, en, g.M);
+    for (int it = 0; it < 4; ++it) side[it] = load_side4<EPI, FULL>(g.out, em0 + fq + 4 * it, en, g.M);
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
+    for (int i = 0; i < TM; ++i) {
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+      for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) patch[(fq * 4 + rr) * PITCH + j * 16 + frow] = acc[i][j][rr];
-    if (i + 1 < TM) {
+        for (int rr = 0; rr < 4; ++rr) patch[(fq * 4 + rr) * PITCH + j * 16 + frow] = acc[i][j][rr];
+      if (i + 1 < TM) {
 #pragma unroll
-      for (int it = 0; it < 4; ++it) side_next[it] = load_side4<EPI>(g.out, em0 + (i + 1) * 16 + fq + 4 * it, en, g.M);
+        for (int it = 0; it < 4; ++it) side_next[it] = load_side4<EPI, FULL>(g.out, em0 + (i + 1) * 16 + fq + 4 * it, en, g.M);
+      }
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int rl = fq + 4 * it;
+        const float4 v = *reinterpret_cast<const float4*>(patch + rl * PITCH + frow * 4);
+        store_out4<EPI, F16 ? PREC_F16X3 : PREC_BF16X3, FULL>(g.out, em0 + i * 16 + rl, en, v, side[it], bias4, g.M);
+      }
+#pragma unroll
+      for (int it = 0; it < 4; ++it) side[it] = side_next[it];
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int rl = fq + 4 * it;
-      const float4 v = *reinterpret_cast<const float4*>(patch + rl * PITCH + frow * 4);
-      store_out4<EPI, F16 ? PREC_F16X3 : PREC_BF16X3>(g.out, em0 + i * 16 + rl, en, v, side[it], g.M);
-    }
-#pragma unroll
-    for (int it = 0; it < 4; ++it) side[it] = side_next[it];
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  }
+  };
+  // wave-uniform: the whole block tile inside the matrix -> no per-row predicates (and no branches) between the stores
+  if (m0 + T::BM <= g.M && n0 + T::BN <= g.out.n_valid) strips(std::true_type{}); else strips(std::false_type{});
 }
 
 
@@ -467,6 +481,8 @@ __device__ __forceinline__ bf16x8 gload16(unsigned voff, const void* sbase) {
   return v;
 }
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// the same, ordering the consumers of the named fragments behind the wait (an MFMA is not a memory operation: "memory" alone does not hold it back)
+template <int N> __device__ __forceinline__ void wait_vm(bf16x8& f0, bf16x8& f1) { asm volatile("s_waitcnt vmcnt(%2)" : "+v"(f0), "+v"(f1) : "n"(N) : "memory"); }
 // LDS fragment reads with hand-counted waits.  With the inline-asm global loads in the loop the compiler's own waitcnt insertion fell
 // back to s_waitcnt lgkmcnt(0) in front of every consumer (disassembly), i.e. every prefetched fragment waited for the youngest read
 // as well.  lds_read16 issues the read, lgkm_wait<N>(frag) waits until at most N younger LDS operations are outstanding; taking the
@@ -534,28 +550,40 @@ __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, CFG::WM * CFG::WN == 4 ? 2 
   const char *w16b[TN], *w8b[TN], *wl8b[TN];       // block of n-tile j at the current K-tile
   const unsigned wl16 = lane * 16, wl32 = lane * 32;
   int si = 0, kk = 0, nk = 0;
+#ifdef AWT_DIAG_SAME_TILE   // every workgroup streams the operand tiles of tile (0, 0): 100 % L2 hits (timing-only, wrong results)
+  const int am0 = 0, an0 = 0;
+#else
+  const int am0 = m0, an0 = n0;
+#endif
   auto open_segment = [&](int seg) {
     si = seg; kk = 0;
     const GemmSeg& sg = g.seg[seg];
     nk = sg.K / BK;
+    // The per-lane offsets are 32-bit and RELATIVE to the first source row of the tile, which goes into the 64-bit (SGPR) plane bases: a tile
+    // spans at most 128 row_mul + 2 source rows, so the offsets stay small however large the activation planes are (a plane of 64+ clips of
+    // Whisper-large's MLP hidden exceeds 4 GiB; offsets from the plane base overflowed there).
+    const int mb = am0 < g.M ? am0 : g.M - 1;
+    const int grp0 = mb / sg.rows_out;
+    const int sr0 = (mb - grp0 * sg.rows_out) * sg.row_mul + sg.row_add;
+    const int64_t base_row = (int64_t)grp0 * sg.rows_in + (sr0 > 0 ? sr0 : 0);       // wave-uniform; every valid source row of the tile is >= it
 #pragma unroll
     for (int it = 0; it < IT16; ++it) {
       const int p = it * NT + tid, row = p >> 3, c = (p & 7) ^ ((row >> 1) & 7);
-      int m = m0 + row; m = m < g.M ? m : g.M - 1;
+      int m = am0 + row; m = m < g.M ? m : g.M - 1;
       const int grp = m / sg.rows_out, r = m - grp * sg.rows_out;
       const int sr = r * sg.row_mul + sg.row_add;
-      a16o[it] = (sr >= 0 && sr < sg.rows_in) ? (unsigned)((((int64_t)grp * sg.rows_in + sr) * sg.lda + c * 8) * 2) : kInvalid;
+      a16o[it] = (sr >= 0 && sr < sg.rows_in) ? (unsigned)((((int64_t)grp * sg.rows_in + sr - base_row) * sg.lda + c * 8) * 2) : kInvalid;
     }
 #pragma unroll
     for (int it = 0; it < IT8; ++it) {
       const int p = it * NT + tid, row = p >> 2, c = (p & 3) ^ ((row >> 2) & 3);
-      int m = m0 + row; m = m < g.M ? m : g.M - 1;
+      int m = am0 + row; m = m < g.M ? m : g.M - 1;
       const int grp = m / sg.rows_out, r = m - grp * sg.rows_out;
       const int sr = r * sg.row_mul + sg.row_add;
-      a8o[it] = (sr >= 0 && sr < sg.rows_in) ? (unsigned)(((int64_t)grp * sg.rows_in + sr) * sg.lda + c * 16) : kInvalid;
+      a8o[it] = (sr >= 0 && sr < sg.rows_in) ? (unsigned)(((int64_t)grp * sg.rows_in + sr - base_row) * sg.lda + c * 16) : kInvalid;
     }
-    a16b = (const char*)sg.a_hi; a8b = (const char*)sg.a8; al8b = (const char*)sg.al8;
-    const int nt0 = (n0 >> 5) + wc * TN;
+    a16b = (const char*)sg.a_hi + base_row * sg.lda * 2; a8b = (const char*)sg.a8 + base_row * sg.lda; al8b = (const char*)sg.al8 + base_row * sg.lda;
+    const int nt0 = (an0 >> 5) + wc * TN;
     const int64_t w16_ts = (int64_t)sg.w_ksteps * 2 * 1024;          // bytes per 32-row n-tile of the fp16 plane: (K / 16) blocks of 1 KB
     const int64_t w8_ts = (int64_t)(sg.w_ksteps / 2) * 2048;         // bytes per n-tile of an e4m3 plane: (K / 64) blocks of 2 KB
 #pragma unroll
@@ -673,6 +701,12 @@ __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, CFG::WM * CFG::WN == 4 ? 2 
         // LDS operations younger than this step's fragment: the (up to) three fragments read ahead, plus the first e4m3 reads
         constexpr int AHEAD = (4 * TM - 1 - S < AD ? 4 * TM - 1 - S : AD) + (EARLY8 && !WX && S >= 4 * TM - 2 ? 2 : 0) + (EARLY8 && S >= 4 * TM - 1 ? 2 : 0);
         lgkm_wait<AHEAD>(af[S % (AD + 1)]);
+#if AWT_GEMM_WDEC
+        // the fp16 W fragments of k-step ks were loaded a whole K-tile ago (ring); vmcnt retires in issue order, so the wait counts what was
+        // issued since: the later k-steps' fragments of this K-tile (3 - ks) TN, its e4m3 planes NW8, and -- when prefetching -- the DMA
+        // pieces (all of them from k-step 1 on, this step's share in k-step 0) and the ks TN fragments already reloaded for K-tile kt + 1
+        if constexpr (i == 0) wait_vm<(PF ? 3 * TN + NW8 + (ks == 0 ? DMA_PER_STEP : NDMA) : (3 - ks) * TN + NW8)>(w16[ks][0], w16[ks][1]);
+#endif
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = mfma32<true>(af[S % (AD + 1)], w16[ks][j], acc[i][j]);
@@ -716,8 +750,14 @@ __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, CFG::WM * CFG::WN == 4 ? 2 
     }(std::make_integer_sequence<int, TM>{});
     if constexpr (PF) {
       load_w8();
+#if AWT_GEMM_WDEC
+      // only the DMA pieces of K-tile kt + 1 must have landed before the barrier; its W fragments (NW16 + NW8 younger loads) stay in flight
+      // across it and are waited for where they are consumed, a K-tile after their issue
+      wait_vm<NW16 + NW8>();
+#else
       // the DMA pieces and the fp16 W fragments of K-tile kt + 1 are older than the NW8 e4m3 loads just issued
       wait_vm<NW8>();
+#endif
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -751,29 +791,47 @@ __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, CFG::WM * CFG::WN == 4 ? 2 
   float* patch = reinterpret_cast<float*>(smem) + wave * (32 * PITCH);      // 9216 B per wave
   const int c8 = (lane & 7) * 8, r8 = lane >> 3;
   const int em0 = m0 + wr * TM * 32, en = n0 + wc * 64 + c8;
+  float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+  if (g.out.bias && en < g.out.n_valid) { b0 = *reinterpret_cast<const float4*>(g.out.bias + en); b1 = *reinterpret_cast<const float4*>(g.out.bias + en + 4); }
+  constexpr bool SIDE = EPI == EPI_F32_RESID || EPI == EPI_F32_GELU_POS;
+  auto strips = [&](auto full_t) {
+    constexpr bool FULL = decltype(full_t)::value;
+    float4 side[4][2], side_next[4][2];
+    auto load_sides = [&](float4 (&d)[4][2], int i) {
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
+      for (int it = 0; it < 4; ++it) {
+        d[it][0] = load_side4<EPI, FULL>(g.out, em0 + i * 32 + r8 + 8 * it, en, g.M);
+        d[it][1] = load_side4<EPI, FULL>(g.out, em0 + i * 32 + r8 + 8 * it, en + 4, g.M);
+      }
+    };
+    if constexpr (SIDE) load_sides(side, 0);
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+    for (int i = 0; i < TM; ++i) {
 #pragma unroll
-      for (int rr = 0; rr < 16; ++rr) patch[((rr & 3) + 8 * (rr >> 2) + 4 * half) * PITCH + j * 32 + r32] = acc[i][j][rr];
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    float4 side[4][2];
+      for (int j = 0; j < TN; ++j)
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      side[it][0] = load_side4<EPI>(g.out, em0 + i * 32 + r8 + 8 * it, en, g.M);
-      side[it][1] = load_side4<EPI>(g.out, em0 + i * 32 + r8 + 8 * it, en + 4, g.M);
+        for (int rr = 0; rr < 16; ++rr) patch[((rr & 3) + 8 * (rr >> 2) + 4 * half) * PITCH + j * 32 + r32] = acc[i][j][rr];
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      // the side inputs (residual rows, positional rows) of the NEXT strip are requested before this strip's stores: vmcnt retires in issue
+      // order, so a load issued behind the stores would wait for their acknowledgement
+      if constexpr (SIDE) { if (i + 1 < TM) load_sides(side_next, i + 1); }
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int rl = r8 + 8 * it;
+        const float4 v0 = *reinterpret_cast<const float4*>(patch + rl * PITCH + c8), v1 = *reinterpret_cast<const float4*>(patch + rl * PITCH + c8 + 4);
+        store_out8_f8<EPI, FULL>(g.out, em0 + i * 32 + rl, en, v0, v1, side[it][0], side[it][1], b0, b1, g.M);
+      }
+      if constexpr (SIDE) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) { side[it][0] = side_next[it][0]; side[it][1] = side_next[it][1]; }
+      }
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int rl = r8 + 8 * it;
-      const float4 v0 = *reinterpret_cast<const float4*>(patch + rl * PITCH + c8), v1 = *reinterpret_cast<const float4*>(patch + rl * PITCH + c8 + 4);
-      store_out8_f8<EPI>(g.out, em0 + i * 32 + rl, en, v0, v1, side[it][0], side[it][1], g.M);
-    }
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  }
+  };
+  // wave-uniform: the whole block tile inside the matrix (every tile of the encoder's shapes; only a ragged last row panel takes the other path)
+  if (m0 + BM <= g.M && n0 + BN <= g.out.n_valid) strips(std::true_type{}); else strips(std::false_type{});
 }
 
 template <int EPI, class CFG>
@@ -798,6 +856,7 @@ int launch_f8(GemmArgs a, hipStream_t s) {
 }
 
 
+#ifdef AWT_EXPERIMENTAL_F6   // round-2 experiment: not compiled into the shipped library
 // ================================================================================================ PREC_F16F6 (experimental)
 // The f16f8 kernel with the two correction planes in FP6 e3m2: per fragment pair the fp16 product (4 x 32 pipe cycles per 64-deep K-tile and
 // 32 x 32 tile) plus two block-scaled FP6 products of 32 cycles each = 1.5 bf16-MFMA-equivalents instead of 2, and 3.5 instead of 4 operand
@@ -997,11 +1056,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f6_kernel(GemmArgs g) {
   for (int kt = 0; kt + 1 < ktiles; ++kt) ktile(std::true_type{}, kt);
   ktile(std::false_type{}, ktiles - 1);
 
-  // ---- epilogue: as gemm_f8_kernel
+  // ---- epilogue: as gemm_f8_kernel (predicated form)
   constexpr int PITCH = 72;
   float* patch = reinterpret_cast<float*>(smem) + wave * (32 * PITCH);
   const int c8 = (lane & 7) * 8, r8 = lane >> 3;
   const int em0 = m0, en = n0 + wc * 64 + c8;
+  float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+  if (g.out.bias && en < g.out.n_valid) { b0 = *reinterpret_cast<const float4*>(g.out.bias + en); b1 = *reinterpret_cast<const float4*>(g.out.bias + en + 4); }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -1020,7 +1081,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f6_kernel(GemmArgs g) {
     for (int it = 0; it < 4; ++it) {
       const int rl = r8 + 8 * it;
       const float4 v0 = *reinterpret_cast<const float4*>(patch + rl * PITCH + c8), v1 = *reinterpret_cast<const float4*>(patch + rl * PITCH + c8 + 4);
-      store_out8_f8<EPI>(g.out, em0 + i * 32 + rl, en, v0, v1, side[it][0], side[it][1], g.M);
+      store_out8_f8<EPI, false>(g.out, em0 + i * 32 + rl, en, v0, v1, side[it][0], side[it][1], b0, b1, g.M);
     }
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1038,6 +1099,8 @@ int launch_f6(GemmArgs a, hipStream_t s) {
   AWT_HIP_CHECK(hipGetLastError());
   return AWT_OK;
 }
+
+#endif  // AWT_EXPERIMENTAL_F6
 
 int g_force_tile = 0;  // 0 = auto, 64 / 128 / 256 = forced (tuning and tests)
 // Tile order (see the kernel).  Measured on the encoder's shapes (tools/gemm_traffic_shapes.sh, profiles/r01_gemm_tile_order.txt):
@@ -1066,6 +1129,9 @@ constexpr int kSlots = 512;
 template <int EPI>
 int launch_epi(GemmArgs a, int prec, hipStream_t s) {
   if (prec == PREC_F16F6) {
+#ifndef AWT_EXPERIMENTAL_F6
+    return awt_fail(AWT_ERR_INVALID, "gemm (f16f6): the FP6 cross-term experiment is not part of this build (compile with -DAWT_EXPERIMENTAL_F6)");
+#else
     if constexpr (EPI == EPI_F32 || EPI == EPI_F32_RESID) {
       if (a.nseg != 1 || a.N % 256 != 0 || a.seg[0].rows_out != a.M || a.seg[0].rows_in != a.M || a.seg[0].row_mul != 1 || a.seg[0].row_add != 0)
         return awt_fail(AWT_ERR_INVALID, "gemm (f16f6): one plain K segment and N % 256 == 0 only");
@@ -1073,6 +1139,7 @@ int launch_epi(GemmArgs a, int prec, hipStream_t s) {
       if (gap <= 0 || gap >= (1ll << 31)) return awt_fail(AWT_ERR_INVALID, "gemm (f16f6): the lo6 plane must follow the hi6 plane within 2 GB");
       return launch_f6<EPI>(a, s);
     } else return awt_fail(AWT_ERR_INVALID, "gemm (f16f6): fp32 outputs only (experimental single-operator path)");
+#endif
   }
   if (prec == PREC_F16F8) {
     if constexpr (EPI == EPI_BF16_GELU_SAVE || EPI == EPI_BF16_DGELU) return awt_fail(AWT_ERR_INVALID, "gemm: the training epilogues have no f16f8 form");

@@ -98,15 +98,34 @@ class _EncoderLoRAFunction(torch.autograd.Function):
 
 
 class _Leaf(nn.Module):
-    """Parameter holder so that state-dict keys read `<path>.weight` / `.bias` / `.lora_A` / `.lora_B`."""
+    """Parameter holder so that state-dict keys read `<path>.weight` / `.bias` / `.lora_A` / `.lora_B`.  `epoch` is a one-element list
+    shared with the owning encoder: replacing or deleting a Parameter object bumps it (NativeWhisperEncoder.sync_weights)."""
+
+    def __init__(self, epoch=None):
+        super().__init__()
+        object.__setattr__(self, "_awt_epoch", epoch if epoch is not None else [0])
+
+    def register_parameter(self, name, param):
+        super().register_parameter(name, param)
+        self._awt_epoch[0] += 1
+
+    def __setattr__(self, name, value):
+        if isinstance(value, nn.Parameter) or name in self.__dict__.get("_parameters", ()):
+            self._awt_epoch[0] += 1
+        super().__setattr__(name, value)
+
+    def __delattr__(self, name):
+        if name in self.__dict__.get("_parameters", ()):
+            self._awt_epoch[0] += 1
+        super().__delattr__(name)
 
 
-def _attach(root: nn.Module, dotted: str, p: nn.Parameter) -> None:
+def _attach(root: nn.Module, dotted: str, p: nn.Parameter, epoch=None) -> None:
     parts = dotted.split(".")
     mod = root
     for name in parts[:-1]:
         if not hasattr(mod, name):
-            mod.add_module(name, _Leaf())
+            mod.add_module(name, _Leaf(epoch))
         mod = getattr(mod, name)
     mod.register_parameter(parts[-1], p)
 
@@ -141,19 +160,21 @@ class NativeWhisperEncoder(nn.Module):
                                       encoder_ffn_dim=cfg.ffn, num_mel_bins=cfg.n_mels,
                                       max_source_positions=cfg.max_source_positions)
         dev = torch.device(device)
+        self._epoch = [0]            # bumped by every leaf whose Parameter objects change (see _Leaf)
         base = init_encoder_weights(cfg, seed or 0, init_profile) if seed is not None else None
         for name, shape in encoder_param_shapes(cfg):
             t = torch.from_numpy(base[name]) if base is not None else torch.zeros(shape)
-            _attach(self, name, nn.Parameter(t.to(dev), requires_grad=False))
+            _attach(self, name, nn.Parameter(t.to(dev), requires_grad=False), self._epoch)
         if lora is not None:
             lw = init_lora_weights(cfg, lora, seed or 0) if seed is not None else None
             for name, shape in lora_param_shapes(cfg, lora):
                 t = torch.from_numpy(lw[name]) if lw is not None else torch.zeros(shape)
-                _attach(self, name, nn.Parameter(t.to(dev), requires_grad=True))
+                _attach(self, name, nn.Parameter(t.to(dev), requires_grad=True), self._epoch)
         self._handle = None
         self._chunk = chunk_clips
         self._synced: Dict[str, int] = {}
         self._param_cache = None
+        self._param_ids = None
         self._ws: Optional[torch.Tensor] = None
         # bound gradient buffer (bind_grad_buffer) and the communicator its exchange runs on (set_comm)
         self._grad_flat: Optional[torch.Tensor] = None
@@ -227,8 +248,14 @@ class NativeWhisperEncoder(nn.Module):
         self._ensure_handle()
         L = _lib.lib()
         n = 0
-        if self._param_cache is None:      # walking the module tree costs more than the version checks: do it once
+        # walking the module tree costs more than the version checks, so the (name, parameter) list is cached; every leaf bumps a shared
+        # epoch when one of its Parameter OBJECTS is replaced (`layer.fc1.weight = nn.Parameter(...)`, pruning / parametrize utilities),
+        # which neither load_state_dict nor _apply sees -- a stale list would keep checking the OLD tensors' versions and run on stale weights
+        if self._param_cache is None or self._param_ids != self._epoch[0]:
             self._param_cache = list(self.named_parameters())
+            if self._param_ids is not None and self._param_ids != self._epoch[0]:
+                self._synced.clear()
+            self._param_ids = self._epoch[0]
         if not force and all(self._synced.get(name) == p._version for name, p in self._param_cache):
             return 0
         if self._auto_precision and not fresh and any(self._synced.get(name) != p._version and "lora_" not in name for name, p in self._param_cache):
@@ -248,6 +275,14 @@ class NativeWhisperEncoder(nn.Module):
                 self._synced[name] = ver
                 n += 1
         return n
+
+    def exact16_matrices(self):
+        """(projection matrices whose weights are all fp16-representable, projection matrices): what the library found at upload time and
+        therefore which GEMM form each matrix runs (include/awt.h: awt_encoder_exact16_matrices)."""
+        self.sync_weights()
+        ex, tot = C.c_int(), C.c_int()
+        _lib.check(_lib.lib().awt_encoder_exact16_matrices(self._handle, C.byref(ex), C.byref(tot)))
+        return ex.value, tot.value
 
     # ------------------------------------------------------------------------------------------------ gradients
     def lora_parameters_library_order(self) -> list:

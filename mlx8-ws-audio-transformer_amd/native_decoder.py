@@ -133,6 +133,10 @@ def attention_small_backward(q, ldq, k, ldk, v, ldv, o, dout, lse, dq, dk, dv, B
 def cross_entropy(logits, labels, vocab):
     """(loss scalar tensor, dlogits [M, ld]) of CrossEntropyLoss(ignore_index=-100) over the first `vocab` columns."""
     M, ld = logits.shape
+    flat = labels.reshape(-1)
+    bad = (flat != -100) & ((flat < 0) | (flat >= vocab))              # torch.nn.CrossEntropyLoss raises for these; so do we (only -100 is ignored)
+    if bool(bad.any()):
+        raise IndexError(f"Target {int(flat[bad][0])} is out of bounds.")
     loss = torch.empty((), dtype=torch.float32, device=logits.device)
     dlogits = torch.empty_like(logits)
     scratch = torch.empty(M + 1, dtype=torch.float32, device=logits.device)

@@ -44,3 +44,69 @@ def test_more_gpus_than_visible_is_an_error_not_a_silent_single_gpu_run():
 def test_world_size_mismatch_is_refused():
     r = _run("--gpus", "2", "--workload", "noop", env={"WORLD_SIZE": "1", "RANK": "0"})
     assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
+
+
+def test_launcher_parent_imports_no_torch_and_counts_gpus_from_sysfs():
+    """the process that starts the ranks must never initialise the GPU.  `bench.visible_gpus()` reads sysfs only;
+    spawning N ranks does not pull torch (or anything HIP) into the parent."""
+    code = ("import sys, bench\n"
+            "n = bench.visible_gpus()\n"
+            "assert isinstance(n, int) and n >= 0\n"
+            "assert 'torch' not in sys.modules and 'ctypes' not in sys.modules, sorted(m for m in sys.modules if 'torch' in m)\n"
+            "import inspect\n"
+            "assert 'import torch' not in inspect.getsource(bench.spawn_ranks)\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+
+
+def test_a_failing_rank_ends_the_others_quickly(tmp_path):
+    """the launcher polls every rank; one rank's failure kills the rest instead of waiting for rank 0's collective to time out."""
+    import time
+    script = tmp_path / "fake_bench.py"
+    script.write_text("import os, sys, time\n"
+                      "sys.path.insert(0, %r)\n"
+                      "import bench\n"
+                      "if 'WORLD_SIZE' in os.environ:\n"
+                      "    if os.environ['RANK'] == '1':\n"
+                      "        sys.exit(7)\n"
+                      "    time.sleep(600)\n"
+                      "class A: gpus = 2; dist_backend = 'gloo'; workload = 'noop'\n"
+                      "bench.__file__ = __file__\n"
+                      "sys.exit(bench.spawn_ranks(A()))\n" % ROOT)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 7 and time.time() - t0 < 60, (r.returncode, r.stderr[-500:])
+
+
+def test_power_is_read_from_sysfs_without_any_child_process(tmp_path):
+    """package power / shader clock come from hwmon + pp_dpm_sclk files, read by a thread: no rocm-smi, no exec; and no
+    sampler at all under a profiler preload."""
+    sys.path.insert(0, ROOT)
+    import bench
+    dev = tmp_path / "card1" / "device"
+    (dev / "hwmon" / "hwmon3").mkdir(parents=True)
+    (dev / "hwmon" / "hwmon3" / "power1_average").write_text("1364000000\n")
+    (dev / "pp_dpm_sclk").write_text("0: 132Mhz\n1: 1917Mhz *\n2: 2400Mhz\n")
+    idle = tmp_path / "card0" / "device"
+    (idle / "hwmon" / "hwmon1").mkdir(parents=True)
+    (idle / "hwmon" / "hwmon1" / "power1_average").write_text("95000000\n")
+    (idle / "pp_dpm_sclk").write_text("0: 132Mhz *\n")
+    assert bench.read_power_sysfs(str(tmp_path)) == (1364.0, 1917)
+    assert bench.read_power_sysfs(str(tmp_path / "nothing")) is None
+    import inspect
+    src = inspect.getsource(bench.PowerSampler) + inspect.getsource(bench.read_power_sysfs)
+    assert "subprocess" not in src and "Popen" not in src and "os.exec" not in src and "os.system" not in src
+    s = bench.PowerSampler(root=str(tmp_path), period=0.01)
+    import time
+    time.sleep(0.1)
+    s.close()
+    assert s.thread is not None and len(s.rows) >= 2 and s.rows[0][1:] == (1364.0, 1917)
+    old = os.environ.get("ROCP_TOOL_LIBRARIES")
+    os.environ["ROCP_TOOL_LIBRARIES"] = "/opt/rocm/lib/librocprofiler-sdk-tool.so"
+    try:
+        assert bench.profiler_attached() and bench.PowerSampler(root=str(tmp_path)).thread is None
+    finally:
+        if old is None:
+            os.environ.pop("ROCP_TOOL_LIBRARIES")
+        else:
+            os.environ["ROCP_TOOL_LIBRARIES"] = old

@@ -333,3 +333,22 @@ def test_encoder_with_forced_attention_forms(shape):
     e = oracle_enc.error_norms(out, ref)
     print(shape, e)
     assert e["max_abs"] < 3e-4, e
+
+
+def test_a_replaced_parameter_object_is_pushed_to_the_library():
+    """`layer.fc1.weight = nn.Parameter(...)` (pruning / parametrize utilities do this) replaces the Parameter OBJECT without
+    going through load_state_dict or _apply; the cached parameter list must not keep the library on the old weights."""
+    cfg = wts.config("mini", True)
+    enc = _native(cfg, "bf16x3")
+    mel = torch.from_numpy(_mel(cfg, 1)).cuda()
+    before = enc(mel).last_hidden_state.clone()
+    W = {k: v.copy() for k, v in wts.init_encoder_weights(cfg, 0, "test").items()}
+    W["layers.0.fc1.weight"] = wts.init_encoder_weights(cfg, 9, "test")["layers.0.fc1.weight"]
+    enc.layers[0].fc1.weight = torch.nn.Parameter(torch.from_numpy(W["layers.0.fc1.weight"]).cuda(), requires_grad=False)
+    after = enc(mel).last_hidden_state
+    ref = oracle_enc.encoder_forward(W, mel.cpu().numpy(), cfg.heads).numpy()
+    assert float((after - before).abs().max()) > 1e-3          # the new weights are really in use
+    assert np.abs(after.cpu().numpy() - ref).max() < PARITY_TOL
+    del enc.layers[0].fc1.weight                                 # deleting one is seen as well (the forward then fails loudly, not stalely)
+    with pytest.raises(Exception):
+        enc(mel)

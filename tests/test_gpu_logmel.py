@@ -100,3 +100,29 @@ def test_urbansound_batch_and_prepare():
     out = urbansound.mel_spectrogram_log(batch, n_mels=80).cpu().numpy()
     for i in range(3):
         np.testing.assert_allclose(out[i], oracle.urbansound_logmel(clips[i], n_mels=80), rtol=0, atol=MEL_TOL)
+
+
+def test_prepare_dataset_through_the_native_processor():
+    """Scope row a1 end to end: the reference's `prepare_dataset` (AB/fineTune.py:85-92) bound to the native `WhisperProcessor` (HIP log-mel +
+    the note tokenizer) on a seeded clip -> `input_features` [80, 3000] within 1e-5 of the oracle, `labels` exactly the tokenizer's ids; then
+    through the reference's collator."""
+    from mlx8_ws_audio_transformer_amd.collator import DataCollatorSpeechSeq2SeqWithPadding, make_prepare_dataset
+    from mlx8_ws_audio_transformer_amd.feature_extraction import WhisperProcessor
+    from mlx8_ws_audio_transformer_amd.transcribe import NoteTokenizer
+    from tests.util import piano_clips_f32
+    tok = NoteTokenizer()
+    prep = make_prepare_dataset(WhisperProcessor(tokenizer=tok))
+    clips = piano_clips_f32(2, 5)
+    texts = ["<|MIDI|> G#6 F2 C4 <|/MIDI|>", "<|MIDI|> A0 <|/MIDI|>"]
+    rows = [prep({"audio": {"array": c, "sampling_rate": 16000}, "sentence": t}) for c, t in zip(clips, texts)]
+    ref = oracle.whisper_logmel(clips)
+    for r, m, t in zip(rows, ref, texts):
+        f = np.asarray(r["input_features"])
+        assert f.shape == (80, 3000) and f.dtype == np.float32
+        assert np.abs(f - m).max() <= 1e-5
+        assert r["labels"] == tok(t)["input_ids"] and r["labels"][0] == tok.bos_token_id
+    batch = DataCollatorSpeechSeq2SeqWithPadding(processor=WhisperProcessor(tokenizer=tok), decoder_start_token_id=tok.bos_token_id)(rows)
+    assert tuple(batch["input_features"].shape) == (2, 80, 3000)
+    assert batch["labels"].tolist() == [tok(texts[0])["input_ids"][1:], tok(texts[1])["input_ids"][1:] + [-100, -100]]     # BOS stripped, -100 padding
+    with pytest.raises(ValueError):
+        prep({"audio": {"array": clips[0], "sampling_rate": 44100}, "sentence": texts[0]})

@@ -143,3 +143,25 @@ def test_native_decoder_gradients_match_the_torch_decoder():
     ref = res[False][1]
     assert float(ref.abs().max()) > 0
     assert float((res[True][1] - ref).abs().max()) < 2e-3 * float(ref.abs().max())
+
+
+def test_cross_entropy_ignores_only_minus_100():
+    """torch.nn.CrossEntropyLoss (what the reference trains with) ignores -100 and RAISES for any other target outside
+    [0, vocab).  The wrapper raises too; the C-ABI call alone (which cannot fail without a synchronisation) returns a NaN loss instead of
+    silently shrinking the denominator."""
+    import ctypes as C
+    from mlx8_ws_audio_transformer_amd import _lib, native_decoder as nd
+    vocab, ld, M = 1000, 1024, 6
+    logits = _rand((M, ld), 3)
+    good = torch.tensor([5, -100, 999, 0, -100, 17])
+    loss, dl = nd.cross_entropy(logits, good, vocab)
+    ref = F.cross_entropy(logits[:, :vocab].double().cpu(), good, ignore_index=-100)
+    assert abs(float(loss) - float(ref)) < 1e-5
+    for bad in ([5, -100, 1000, 0, -100, 17], [5, -1, 3, 0, -100, 17], [51865, 1, 2, 3, 4, 5]):
+        with pytest.raises(IndexError, match="out of bounds"):
+            nd.cross_entropy(logits, torch.tensor(bad), vocab)
+        lab = torch.tensor(bad, dtype=torch.int64, device="cuda")
+        out, dlog, scratch = torch.zeros((), device="cuda"), torch.empty_like(logits), torch.empty(M + 1, device="cuda")
+        _lib.check(_lib.lib().awt_op_cross_entropy(_lib.ctx(logits.device), _lib.ptr(logits), _lib.ptr(lab), M, vocab, ld, _lib.ptr(out), _lib.ptr(dlog),
+                                                   _lib.ptr(scratch), _lib.stream_handle()))
+        assert torch.isnan(out).item()

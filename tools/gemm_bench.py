@@ -7,7 +7,7 @@ from mlx8_ws_audio_transformer_amd import _lib, ops
 
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 96000
 shapes = [("qkv", M, 2304, 768), ("out", M, 768, 768), ("fc1", M, 3072, 768), ("fc2", M, 768, 3072), ("conv1", 2 * M, 768, 256)]
-for prec in ["bf16x3", "fp16x3", "f16f8", "f16f6", "bf16"]:
+for prec in ["bf16x3", "fp16x3", "f16f8", "bf16"]:
     for name, m, n, k in shapes:
         x = torch.randn(m, k, device="cuda")
         w = torch.randn(n, k, device="cuda") * k ** -0.5
