@@ -470,46 +470,62 @@ def load_bench_weights(torch, enc, W):
     return enc
 
 
+def cpu_budget():
+    """(threads to use, note): the cores this process may actually RUN on = min(affinity mask, cgroup CPU quota).  On the GPU box the mask
+    shows all 256 logical CPUs of the host while the container's share is one GPU's worth of it: the oracle on 256 threads ran 8x SLOWER
+    than on 16 (0.152 vs 1.19 clips/s, 52 s vs 6.6 s per 8-clip pass; gpurun_out/r03/e3_bench.json) -- threads beyond the share only thrash."""
+    avail = len(os.sched_getaffinity(0))
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]                      # cgroup v2
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())                 # cgroup v1
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    share = int(os.environ.get("AWT_CPU_THREADS", "0"))
+    if share <= 0:
+        share = max(1, int(quota)) if quota is not None else min(avail, 16)            # no readable quota: the documented share of a 1-GPU box
+    n = max(1, min(avail, share))
+    return n, "host shows %d logical CPUs; this process' CPU share is %s -> %d torch threads" % (
+        avail, ("%.1f CPUs (cgroup quota)" % quota) if quota is not None else "taken as 16 (one GPU's share of the node; no cgroup quota readable; AWT_CPU_THREADS overrides)", n)
+
+
 def cpu_baseline_and_parity(a, torch, cfg, enc, pcm, pcm_host, out_first):
-    """The oracle (CPU restatement of the reference path) on this host's cores: 1 warm-up + 3 timed passes over a bounded
-    sample, median, for mel alone, encoder alone and end to end -- once with every core this process may use
-    (north_star: "the node's own host cores (count stated)"; that is `value` / `cores`) and once with 16 threads (one GPU's share of the
-    host, round 2's figure, kept beside it); then HIP vs oracle on the same clips."""
+    """The oracle (CPU restatement of the reference path) on the host cores this process owns (cpu_budget(): stated in `cores` /
+    `threads_note`): 1 warm-up + up to 3 timed passes over a bounded sample, median, for mel alone, encoder alone and end
+    to end; the timed passes stop once 45 s of CPU work are spent.  Then HIP vs oracle on the same clips."""
     import numpy as np
     from mlx8_ws_audio_transformer_amd import synth, weights as wts
     from oracle import encoder as oenc, logmel as omel
     n = min(a.cpu_clips, pcm.shape[0])
-    avail = len(os.sched_getaffinity(0))
+    threads, note = cpu_budget()
+    torch.set_num_threads(threads)
     W = bench_weights(cfg, a.weights)
     clips_f32 = [synth.pcm_i16_to_f32(c) for c in pcm_host[:n]]
     med = lambda v: sorted(v)[len(v) // 2]
-
-    def timed(threads, passes):
-        torch.set_num_threads(threads)
-        t_mel, t_enc, ref = [], [], None
-        for it in range(passes + 1):                        # pass 0 is the warm-up
-            t0 = time.perf_counter()
-            mel = omel.whisper_logmel(clips_f32, n_samples=cfg.n_frames * 160)
-            t1 = time.perf_counter()
-            with torch.no_grad():
-                ref = oenc.encoder_forward(W, mel, cfg.heads)
-            t2 = time.perf_counter()
-            if it:
-                t_mel.append(t1 - t0); t_enc.append(t2 - t1)
-        m_mel, m_enc, m_all = med(t_mel), med(t_enc), med([x + y for x, y in zip(t_mel, t_enc)])
-        return {"value": round(n / m_all, 3), "cores": torch.get_num_threads(), "mel_clips_per_s": round(n / m_mel, 3),
-                "encoder_clips_per_s": round(n / m_enc, 3), "mel_s": round(m_mel, 2), "encoder_s": round(m_enc, 2)}, mel, ref
-
-    cap = int(os.environ.get("AWT_CPU_THREADS", "0")) or avail       # AWT_CPU_THREADS caps the all-core leg (small CI hosts)
-    full, mel, ref = timed(min(avail, cap), 3)
-    base = {"value": full["value"], "unit": "clips/s", "cores": full["cores"], "kind": "port",
-            "sample": "%d of the step's clips, fp32, parity mode; 1 warm-up + 3 timed passes, median (mel %.2f s + encoder %.2f s per pass)" % (n, full["mel_s"], full["encoder_s"]),
-            "threads_note": "torch threads = every core available to this process (%d)" % avail,
-            "mel_clips_per_s": full["mel_clips_per_s"], "encoder_clips_per_s": full["encoder_clips_per_s"]}
-    if full["cores"] > 16:
-        t16, _, _ = timed(16, 2)
-        base["with_16_threads"] = {"value": t16["value"], "cores": t16["cores"], "mel_clips_per_s": t16["mel_clips_per_s"], "encoder_clips_per_s": t16["encoder_clips_per_s"],
-                                   "note": "the same sample on 16 threads (one GPU's share of the host: round 2's figure); 1 warm-up + 2 timed passes"}
+    t_mel, t_enc, spent = [], [], 0.0
+    for it in range(4):                                     # pass 0 is the warm-up
+        t0 = time.perf_counter()
+        mel = omel.whisper_logmel(clips_f32, n_samples=cfg.n_frames * 160)
+        t1 = time.perf_counter()
+        with torch.no_grad():
+            ref = oenc.encoder_forward(W, mel, cfg.heads)
+        t2 = time.perf_counter()
+        if it:
+            t_mel.append(t1 - t0); t_enc.append(t2 - t1)
+            spent += t2 - t0
+            if spent > 45.0:
+                break
+    m_mel, m_enc, m_all = med(t_mel), med(t_enc), med([x + y for x, y in zip(t_mel, t_enc)])
+    base = {"value": round(n / m_all, 3), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d of the step's clips, fp32, parity mode; 1 warm-up + %d timed passes, median (mel %.2f s + encoder %.2f s per pass)" % (n, len(t_enc), m_mel, m_enc),
+            "threads_note": note, "mel_clips_per_s": round(n / m_mel, 3), "encoder_clips_per_s": round(n / m_enc, 3)}
     hid, feats = enc.encode_pcm(pcm[:n], return_features=True)
     e = oenc.error_norms(hid.cpu().numpy(), ref.numpy())
     parity = {"mel_max_abs": float(np.abs(feats.cpu().numpy() - mel).max()), "mel_tolerance": 1e-5,

@@ -109,15 +109,31 @@ __device__ __forceinline__ f32x16 mfma32_f8(i32x8 a, i32x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, SA, 0, SB);
 }
 __host__ __device__ constexpr float pow2f(int e) { return e >= 0 ? (float)(1ull << e) : 1.0f / (float)(1ull << -e); }
-// four floats -> four e4m3 bytes of x 2^S (round to nearest even; v_cvt_pk_fp8_f32 turns |x| > 464 into NaN, so clamp first)
+// four floats -> four e4m3 bytes of x 2^S (round to nearest even).  Neither conversion instruction saturates -- |x 2^S| > 464 comes out as
+// NaN from v_cvt_pk_fp8_f32 and from v_cvt_scalef32_pk_fp8_f32 alike (tools/fp8_cvt_probe.hip, profiles/r03_fp8_cvt_probe.txt) -- so the
+// value is clamped first, to +-448 2^-S, and the power-of-two scale is applied by the scaled conversion itself (it divides by its scale
+// operand): three instructions per pair instead of five, the same bytes for every input (the probe compares the two forms over every
+// rounding boundary of 33 binades).
 template <int S>
 __device__ __forceinline__ unsigned fp8x4(float a, float b, float c, float d) {
-  constexpr float sc = pow2f(S);
-  a = __builtin_amdgcn_fmed3f(a * sc, -448.f, 448.f); b = __builtin_amdgcn_fmed3f(b * sc, -448.f, 448.f);
-  c = __builtin_amdgcn_fmed3f(c * sc, -448.f, 448.f); d = __builtin_amdgcn_fmed3f(d * sc, -448.f, 448.f);
-  int r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
-  r = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
-  return (unsigned)r;
+  typedef short s16x2_t __attribute__((ext_vector_type(2)));
+  constexpr float lim = 448.0f * pow2f(-S), inv = pow2f(-S);
+  a = __builtin_amdgcn_fmed3f(a, -lim, lim); b = __builtin_amdgcn_fmed3f(b, -lim, lim);
+  c = __builtin_amdgcn_fmed3f(c, -lim, lim); d = __builtin_amdgcn_fmed3f(d, -lim, lim);
+  s16x2_t r = {0, 0};
+  r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(r, a, b, inv, false);
+  r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(r, c, d, inv, true);
+  return __builtin_bit_cast(unsigned, r);
+}
+// the same with the exponent chosen at run time: inv = 2^-S, lim = 448 2^-S (the GEMM epilogue picks S per output column block: q | k, v)
+__device__ __forceinline__ unsigned fp8x4_rt(float a, float b, float c, float d, float lim, float inv) {
+  typedef short s16x2_t __attribute__((ext_vector_type(2)));
+  a = __builtin_amdgcn_fmed3f(a, -lim, lim); b = __builtin_amdgcn_fmed3f(b, -lim, lim);
+  c = __builtin_amdgcn_fmed3f(c, -lim, lim); d = __builtin_amdgcn_fmed3f(d, -lim, lim);
+  s16x2_t r = {0, 0};
+  r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(r, a, b, inv, false);
+  r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(r, c, d, inv, true);
+  return __builtin_bit_cast(unsigned, r);
 }
 // the three planes of four consecutive f16f8 elements: fp16 bits (two dwords), hi8 dword, lo8 dword
 template <int S>

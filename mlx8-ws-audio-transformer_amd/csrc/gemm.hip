@@ -193,11 +193,11 @@ __device__ __forceinline__ void store_out4(const GemmOut& o, int m, int n, float
     *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
   } else {
     int64_t off;
-    float f8s = pow2f(kF8Act);          // PREC_F16F8: scale of the e4m3 planes by operand role
+    float inv8 = pow2f(-kF8Act), lim8 = 448.0f * pow2f(-kF8Act);          // PREC_F16F8: exponent of the e4m3 planes by operand role (store_out8_f8)
     if (EPI == EPI_QKV) {
       const int d = o.H * 64;
       const int which = n / d, within = n - which * d;
-      f8s = which == 0 ? pow2f(kF8Q) : pow2f(kF8KV);
+      inv8 = which == 0 ? pow2f(-kF8Q) : pow2f(-kF8KV); lim8 = which == 0 ? 448.0f * pow2f(-kF8Q) : 448.0f * pow2f(-kF8KV);
       const int h = within >> 6, e = within & 63;
       const int b = m / o.S, s = m - b * o.S;
       if (which == 0) { v[0] *= o.scale; v[1] *= o.scale; v[2] *= o.scale; v[3] *= o.scale; }
@@ -225,10 +225,10 @@ __device__ __forceinline__ void store_out4(const GemmOut& o, int m, int n, float
     if constexpr (OP == PREC_F16F8) {
       bf16_t h[4]; float l[4];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) { h[t] = f32_to_f16(v[t]); l[t] = (v[t] - f16_to_f32(h[t])) * (f8s * pow2f(kF8Lo)); }
+      for (int t = 0; t < 4; ++t) { h[t] = f32_to_f16(v[t]); l[t] = v[t] - f16_to_f32(h[t]); }
       *reinterpret_cast<uint2*>(o.hi + off) = make_uint2(pack2(h[0], h[1]), pack2(h[2], h[3]));
-      *reinterpret_cast<unsigned*>(o.hi8 + off) = fp8x4<0>(v[0] * f8s, v[1] * f8s, v[2] * f8s, v[3] * f8s);
-      *reinterpret_cast<unsigned*>(o.lo8 + off) = fp8x4<0>(l[0], l[1], l[2], l[3]);
+      *reinterpret_cast<unsigned*>(o.hi8 + off) = fp8x4_rt(v[0], v[1], v[2], v[3], lim8, inv8);
+      *reinterpret_cast<unsigned*>(o.lo8 + off) = fp8x4_rt(l[0], l[1], l[2], l[3], lim8 * pow2f(-kF8Lo), inv8 * pow2f(-kF8Lo));
     } else {
       bf16_t hi[4], lo[4];
 #pragma unroll
@@ -264,11 +264,12 @@ __device__ __forceinline__ void store_out8_f8(const GemmOut& o, int m, int n, fl
     return;
   }
   int64_t off;
-  float f8s = pow2f(kF8Act);
+  // e4m3 planes of x 2^S: the value is clamped to +-448 2^-S and the conversion applies the scale (common.h fp8x4); S by operand role
+  float inv8 = pow2f(-kF8Act), lim8 = 448.0f * pow2f(-kF8Act);
   if (EPI == EPI_QKV) {
     const int d = o.H * 64;
     const int which = n / d, within = n - which * d;
-    f8s = which == 0 ? pow2f(kF8Q) : pow2f(kF8KV);
+    inv8 = which == 0 ? pow2f(-kF8Q) : pow2f(-kF8KV); lim8 = which == 0 ? 448.0f * pow2f(-kF8Q) : 448.0f * pow2f(-kF8KV);
     const int h = within >> 6, e = within & 63;
     const int b = m / o.S, s = m - b * o.S;
     if (which == 0) {
@@ -281,16 +282,17 @@ __device__ __forceinline__ void store_out8_f8(const GemmOut& o, int m, int n, fl
 #pragma unroll
     for (int t = 0; t < 8; ++t) v[t] = EPI == EPI_BF16_GELU ? gelu_erf(v[t]) : v[t] * o.scale;
   }
+  const float invl8 = inv8 * pow2f(-kF8Lo), liml8 = lim8 * pow2f(-kF8Lo);
   bf16_t h[8]; float l[8];
 #pragma unroll
-  for (int t = 0; t < 8; ++t) { h[t] = f32_to_f16(v[t]); l[t] = (v[t] - f16_to_f32(h[t])) * (f8s * pow2f(kF8Lo)); v[t] *= f8s; }
+  for (int t = 0; t < 8; ++t) { h[t] = f32_to_f16(v[t]); l[t] = v[t] - f16_to_f32(h[t]); }
 #ifdef AWT_DIAG_NO_STORE   // timing-only: every store instruction stays, but all waves write the same 1 KB per plane (L2-resident: no HBM write traffic)
   off = (threadIdx.x & 63) * 8;
 #endif
   *reinterpret_cast<uint4*>(o.hi + off) = make_uint4(pack2(h[0], h[1]), pack2(h[2], h[3]), pack2(h[4], h[5]), pack2(h[6], h[7]));
   if (EPI == EPI_QKV && o.skip_v8 && n >= 2 * o.H * 64) return;      // v: fp16 plane only
-  if (o.hi8) *reinterpret_cast<uint2*>(o.hi8 + off) = make_uint2(fp8x4<0>(v[0], v[1], v[2], v[3]), fp8x4<0>(v[4], v[5], v[6], v[7]));   // null: see store_act4
-  *reinterpret_cast<uint2*>(o.lo8 + off) = make_uint2(fp8x4<0>(l[0], l[1], l[2], l[3]), fp8x4<0>(l[4], l[5], l[6], l[7]));
+  if (o.hi8) *reinterpret_cast<uint2*>(o.hi8 + off) = make_uint2(fp8x4_rt(v[0], v[1], v[2], v[3], lim8, inv8), fp8x4_rt(v[4], v[5], v[6], v[7], lim8, inv8));   // null: see store_act4
+  *reinterpret_cast<uint2*>(o.lo8 + off) = make_uint2(fp8x4_rt(l[0], l[1], l[2], l[3], liml8, invl8), fp8x4_rt(l[4], l[5], l[6], l[7], liml8, invl8));
 }
 
 template <int TERMS, int BK, int EPI, class CFG, bool F16, bool WX = false>

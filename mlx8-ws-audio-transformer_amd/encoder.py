@@ -216,6 +216,58 @@ class NativeWhisperEncoder(nn.Module):
         self.precision_report = {"layernorm_gain_ratio": gain, "row_norm_ratio": row, "precision": choice}
         return choice
 
+    # the measured part of the automatic mode: f16f8 is kept only if, on a probe batch, it stays this close (max-abs) to the split-fp16 mode,
+    # which itself sits at the reference's own fp32 noise level.  The north-star bound is 1e-3; a quarter of it leaves room for inputs that
+    # excite the weights more than the probe does.
+    PROBE_TOL = 2.5e-4
+
+    def _probe_features(self) -> torch.Tensor:
+        """Two deterministic probe clips as input features [2, n_mels, T]: a piano-note clip of the synthetic set and broadband noise."""
+        from . import synth
+        from .feature_extraction import logmel_whisper_device
+        from .weights import unit_variates
+        n = self.cfg.n_frames * 160
+        pcm = np.zeros((2, n), dtype=np.float32)
+        clip = synth.pcm_i16_to_f32(synth.synth_clips_i16(1, seed=1234, first=0)[0])
+        m = min(n, clip.size)
+        pcm[0, :m] = clip[:m]
+        pcm[1, :m] = (0.1 * unit_variates("precision_probe", m, 0)).astype(np.float32)
+        return logmel_whisper_device(torch.from_numpy(pcm).to(self.device), max_valid=m, n_frames=self.cfg.n_frames, n_mels=self.cfg.n_mels)
+
+    def _decide_precision(self) -> str:
+        """precision=None: the weight statistics (choose_precision) can only ESCALATE to split-fp16; when they see nothing, the answer is
+        measured: one probe batch through f16f8 and through fp16x3 on these very weights, f16f8 kept if the two agree to PROBE_TOL.  The
+        winner's library handle (weights already uploaded) is kept; cost: one extra weight upload and two 2-clip forwards per load."""
+        choice = self.choose_precision()
+        if choice != DEFAULT_PRECISION:
+            self.precision_report["decided_by"] = "weight statistics"
+            return choice
+        feats = self._probe_features()
+        outs, handles = {}, {}
+        L = _lib.lib()
+        for prec in ("fp16x3", DEFAULT_PRECISION):
+            self.precision = prec
+            self._handle = None
+            self._synced.clear()
+            self._create_handle()
+            self._push_all()
+            ws = _lib.workspace(L.awt_encoder_workspace_bytes(self._handle, feats.shape[0]), self.device)
+            out = torch.empty((feats.shape[0], self.cfg.max_source_positions, self.cfg.d_model), dtype=torch.float32, device=self.device)
+            with torch.cuda.device(self.device):
+                _lib.check(L.awt_encoder_forward(self._handle, _lib.ptr(feats), feats.shape[0], feats.shape[2], _lib.ptr(out), _lib.ptr(ws), ws.numel(),
+                                                 _lib.stream_handle()))
+            outs[prec], handles[prec] = out, (self._handle, dict(self._synced))
+        dist = float((outs[DEFAULT_PRECISION] - outs["fp16x3"]).abs().max())
+        finite = bool(torch.isfinite(outs[DEFAULT_PRECISION]).all())
+        choice = DEFAULT_PRECISION if (finite and dist < self.PROBE_TOL) else "fp16x3"
+        self.precision_report.update({"probe_max_abs_f16f8_vs_fp16x3": dist, "probe_tolerance": self.PROBE_TOL, "precision": choice, "decided_by": "probe"})
+        for prec, (h, synced) in handles.items():
+            if prec == choice:
+                self._handle, self._synced = h, synced
+            else:
+                L.awt_encoder_destroy(h)
+        return choice
+
     def _drop_handle(self):
         if self._handle is not None:
             _lib.lib().awt_encoder_destroy(self._handle)
@@ -227,7 +279,26 @@ class NativeWhisperEncoder(nn.Module):
         if self._handle is not None:
             return
         if self._auto_precision:
-            self.precision = self.choose_precision()
+            self.precision = self._decide_precision()        # the probe leaves the chosen mode's handle in place, weights uploaded
+        if self._handle is None:
+            self._create_handle()
+
+    def _push_all(self) -> int:
+        """Upload every parameter to the current handle (records the versions pushed)."""
+        L = _lib.lib()
+        n = 0
+        with torch.cuda.device(self.device):
+            for name, p in self.named_parameters():
+                t = p.detach()
+                if t.dtype != torch.float32 or not t.is_contiguous():
+                    t = t.float().contiguous()
+                shape = (C.c_int64 * t.dim())(*t.shape)
+                _lib.check(L.awt_encoder_set_weight(self._handle, name.encode(), _lib.ptr(t), shape, t.dim(), _lib.stream_handle()))
+                self._synced[name] = p._version
+                n += 1
+        return n
+
+    def _create_handle(self):
         L = _lib.lib()
         bits = 0
         if self.lora is not None:
@@ -253,15 +324,18 @@ class NativeWhisperEncoder(nn.Module):
         # which neither load_state_dict nor _apply sees -- a stale list would keep checking the OLD tensors' versions and run on stale weights
         if self._param_cache is None or self._param_ids != self._epoch[0]:
             self._param_cache = list(self.named_parameters())
+            want = {n for n, _ in encoder_param_shapes(self.cfg)} | ({n for n, _ in lora_param_shapes(self.cfg, self.lora)} if self.lora is not None else set())
+            have = {n for n, _ in self._param_cache}
+            if have != want:                                   # a parameter was deleted / added behind the module's back: the library would keep stale planes
+                raise KeyError(f"encoder parameters changed: missing {sorted(want - have)[:4]}, unexpected {sorted(have - want)[:4]}")
             if self._param_ids is not None and self._param_ids != self._epoch[0]:
                 self._synced.clear()
             self._param_ids = self._epoch[0]
         if not force and all(self._synced.get(name) == p._version for name, p in self._param_cache):
             return 0
         if self._auto_precision and not fresh and any(self._synced.get(name) != p._version and "lora_" not in name for name, p in self._param_cache):
-            if self.choose_precision() != self.precision:      # new base weights (load_state_dict after a forward) call for the other mode
-                self._drop_handle()
-                self._ensure_handle()
+            self._drop_handle()                                # new base weights (load_state_dict after a forward): decide again, on them
+            self._ensure_handle()
         with torch.cuda.device(self.device):
             for name, p in self._param_cache:
                 ver = p._version

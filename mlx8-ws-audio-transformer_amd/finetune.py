@@ -153,10 +153,18 @@ class WhisperLoRAModel(nn.Module):
     """`model(input_features=..., labels=...) -> .loss, .logits` like WhisperForConditionalGeneration.forward
     (HF:modeling_whisper.py:994-1100): shift labels right, encoder, decoder, tied projection, CE with ignore -100."""
 
-    def __init__(self, cfg: EncoderConfig, lora: LoraSpec, precision: str = "bf16x3", device: str = "cuda", decoder_layers: Optional[int] = None,
+    def __init__(self, cfg: EncoderConfig, lora: Optional[LoraSpec], precision: Optional[str] = "bf16x3", device: str = "cuda", decoder_layers: Optional[int] = None,
                  seed: int = 0, vocab: int = WHISPER_VOCAB, decoder_autocast: Optional[torch.dtype] = None, native_cross_kv: bool = True,
-                 max_target_positions: int = 448, backward_precision: Optional[str] = None, native_decoder: bool = True):
+                 max_target_positions: int = 448, backward_precision: Optional[str] = None, native_decoder: bool = True,
+                 decoder_heads: Optional[int] = None, decoder_ffn: Optional[int] = None, decoder_lora: Optional[LoraSpec] = None):
         super().__init__()
+        # decoder_lora: adapters on the decoder's self- / cross-attention q_proj, v_proj as well (scope row f1: "+ LoRA on decoder"; the
+        # reference fine-tunes every decoder parameter, AB/fineTune.py:131,186-199) -- native decoder only
+        if decoder_lora is not None and (not native_decoder or decoder_autocast is not None):
+            raise ValueError("decoder_lora needs the native decoder (native_decoder=True, no decoder_autocast)")
+        # lora=None: inference only (the reference's wavToWhisper.py / fineTuneMidiTester.py use): the encoder is not trainable and may
+        # run any inference precision (precision=None picks it from the checkpoint, encoder.NativeWhisperEncoder)
+        trainable = lora is not None
         # native_decoder=True (default): decoder, tied projection and cross-entropy run on libawt as well (native_decoder.NativeWhisperDecoder,
         # scope row f1); False keeps the stock-PyTorch decoder (the restatement pinned to HF by tests/golden/decoder.npz) around the
         # native encoder -- kept as the A/B reference of the native one (tests/test_gpu_native_decoder.py)
@@ -167,23 +175,84 @@ class WhisperLoRAModel(nn.Module):
         # decoder_autocast=torch.bfloat16 asks torch to run its matmuls in bf16
         self.decoder_autocast = decoder_autocast
         self.native_cross_kv = native_cross_kv   # False: every decoder matmul on torch (the pre-fusion path, kept for A/B tests)
-        self.precision = precision
-        self.encoder = NativeWhisperEncoder(cfg, precision=precision, lora=lora, device=device, seed=seed, trainable=True,
+        self.encoder = NativeWhisperEncoder(cfg, precision=precision, lora=lora, device=device, seed=seed, trainable=trainable,
                                             backward_precision=backward_precision)
+        self.precision = self.encoder.precision if precision is None else precision
+        dheads, dffn = decoder_heads or cfg.heads, decoder_ffn or cfg.ffn
         torch.manual_seed(seed)
-        self.decoder = WhisperDecoder(cfg.d_model, decoder_layers or cfg.layers, cfg.heads, cfg.ffn, vocab, max_target_positions).to(device)
+        self.decoder = WhisperDecoder(cfg.d_model, decoder_layers or cfg.layers, dheads, dffn, vocab, max_target_positions).to(device)
         if native_decoder:
             from .native_decoder import NativeWhisperDecoder
-            nd = NativeWhisperDecoder(cfg.d_model, decoder_layers or cfg.layers, cfg.heads, cfg.ffn, vocab, max_target_positions,
-                                      precision=precision if precision in ("bf16", "bf16x3") else "bf16x3").to(device)
-            nd.load_state_dict(self.decoder.state_dict())       # the same initial weights as the torch decoder of this seed
+            nd = NativeWhisperDecoder(cfg.d_model, decoder_layers or cfg.layers, dheads, dffn, vocab, max_target_positions,
+                                      precision=precision if precision in ("bf16", "bf16x3") else "bf16x3", lora=decoder_lora, lora_seed=seed).to(device)
+            nd.load_state_dict(self.decoder.state_dict(), strict=decoder_lora is None)       # the same initial weights as the torch decoder of this seed
             self.decoder = nd
-        for p in self.decoder.parameters():
-            p.requires_grad = False             # frozen base model: only the adapters train
+        for n, p in self.decoder.named_parameters():
+            p.requires_grad = "lora_" in n      # frozen base model: only the adapters train
         self.config = SimpleNamespace(decoder_start_token_id=DECODER_START, pad_token_id=PAD_ID, eos_token_id=EOS_ID, d_model=cfg.d_model)
 
     def lora_parameters(self) -> List[nn.Parameter]:
-        return [p for n, p in self.encoder.named_parameters() if "lora_" in n]
+        """Every trainable parameter: the encoder's adapters, then the decoder's (if any)."""
+        return [p for n, p in self.encoder.named_parameters() if "lora_" in n] + [p for n, p in self.decoder.named_parameters() if "lora_" in n]
+
+    @classmethod
+    def from_pretrained(cls, path, lora: Optional[LoraSpec] = None, precision: Optional[str] = None, device: str = "cuda", **kw) -> "WhisperLoRAModel":
+        """`WhisperForConditionalGeneration.from_pretrained(model_path)` for a LOCAL checkpoint directory, as the reference's inference
+        scripts use it (AB/wavToWhisper.py:39,47 `./whisper-small-hi`; AB/fineTuneMidiTester.py:20-21 `./whisper-small-piano`): reads
+        `config.json` and `model.safetensors` / `pytorch_model.bin` (checkpoint.load_checkpoint_dir; no `transformers`, no network), builds
+        the model of that shape and loads encoder and decoder weights under their HF names.  lora=None: inference (precision None = chosen
+        from the checkpoint: f16f8 unless it has outlier channels); a LoraSpec: adapters on the loaded (frozen) base for fine-tuning."""
+        from .checkpoint import encoder_config_from_hf, load_checkpoint_dir
+        hf, enc_sd, dec_sd = load_checkpoint_dir(path)
+        cfg = encoder_config_from_hf(hf, os.path.basename(os.path.normpath(os.fspath(path))))
+        if precision is None and lora is not None:
+            precision = "bf16x3"
+        model = cls(cfg, lora, precision=precision, device=device, decoder_layers=int(hf.get("decoder_layers", cfg.layers)),
+                    vocab=int(hf.get("vocab_size", WHISPER_VOCAB)), max_target_positions=int(hf.get("max_target_positions", 448)),
+                    decoder_heads=int(hf.get("decoder_attention_heads", cfg.heads)), decoder_ffn=int(hf.get("decoder_ffn_dim", cfg.ffn)), **kw)
+        missing, unexpected = model.encoder.load_state_dict(enc_sd, strict=False)
+        missing = [k for k in missing if "lora_" not in k]
+        if missing or unexpected:
+            raise KeyError(f"{path}: encoder state dict mismatch: missing {missing[:4]}, unexpected {list(unexpected)[:4]}")
+        missing, unexpected = model.decoder.load_state_dict(dec_sd, strict=False)
+        if [k for k in missing if "lora_" not in k] or unexpected:
+            raise KeyError(f"{path}: decoder state dict mismatch: missing {[k for k in missing if 'lora_' not in k][:4]}, unexpected {list(unexpected)[:4]}")
+        for n, p in model.decoder.named_parameters():
+            p.requires_grad = "lora_" in n
+        for key, attr in (("decoder_start_token_id", "decoder_start_token_id"), ("pad_token_id", "pad_token_id"), ("eos_token_id", "eos_token_id")):
+            if hf.get(key) is not None:
+                setattr(model.config, attr, int(hf[key]))
+        model.name_or_path = os.fspath(path)
+        return model
+
+    def save_pretrained(self, path, fmt: str = "safetensors") -> str:
+        """Writes the directory `from_pretrained` reads (and `WhisperForConditionalGeneration.from_pretrained` would): config.json + the base
+        weights under `model.encoder.*` / `model.decoder.*`.  Adapters, if any, are MERGED into the projection weights (W + (alpha / r) B A),
+        which is what a downstream loader of the directory expects to find there."""
+        from .checkpoint import save_pretrained_dir
+        enc = {k: v.detach().clone() for k, v in self.encoder.state_dict().items()}
+        if self.encoder.lora is not None:
+            scale = self.encoder.lora.alpha / self.encoder.lora.r
+            for k in [k for k in enc if k.endswith(".lora_A")]:
+                base = k[: -len(".lora_A")]
+                enc[base + ".weight"] = enc[base + ".weight"] + scale * (enc[base + ".lora_B"] @ enc[k])
+            enc = {k: v for k, v in enc.items() if "lora_" not in k}
+        d = self.decoder
+        dec = {k: v.detach().clone() for k, v in d.state_dict().items()}
+        if getattr(d, "lora", None) is not None:
+            for k in [k for k in dec if k.endswith(".lora_A")]:
+                base = k[: -len(".lora_A")]
+                dec[base + ".weight"] = dec[base + ".weight"] + d.lora.scale * (dec[base + ".lora_B"] @ dec[k])
+            dec = {k: v for k, v in dec.items() if "lora_" not in k}
+        cfg = {"architectures": ["WhisperForConditionalGeneration"], "model_type": "whisper", "d_model": self.encoder.cfg.d_model,
+               "encoder_layers": self.encoder.cfg.layers, "encoder_attention_heads": self.encoder.cfg.heads, "encoder_ffn_dim": self.encoder.cfg.ffn,
+               "num_mel_bins": self.encoder.cfg.n_mels, "max_source_positions": self.encoder.cfg.max_source_positions,
+               "decoder_layers": len(d.layers), "decoder_attention_heads": d.layers[0].self_attn.heads if hasattr(d.layers[0].self_attn, "heads") else d.heads,
+               "decoder_ffn_dim": d.layers[0].fc1.weight.shape[0], "vocab_size": d.embed_tokens.weight.shape[0],
+               "max_target_positions": d.embed_positions.weight.shape[0], "decoder_start_token_id": self.config.decoder_start_token_id,
+               "pad_token_id": self.config.pad_token_id, "eos_token_id": self.config.eos_token_id, "activation_function": "gelu",
+               "scale_embedding": False, "torch_dtype": "float32"}
+        return save_pretrained_dir(os.fspath(path), cfg, enc, dec, fmt=fmt)
 
     def forward(self, input_features: torch.Tensor, labels: Optional[torch.Tensor] = None, decoder_input_ids: Optional[torch.Tensor] = None):
         if decoder_input_ids is None:
@@ -443,20 +512,28 @@ class Seq2SeqTrainer:
                 better = best is None or (score > best if self.args.greater_is_better and key in m else score < best)
                 if better:
                     best = score
-                    best_state = {k: v.detach().clone() for k, v in self.model.encoder.state_dict().items() if "lora_" in k}
+                    best_state = ({k: v.detach().clone() for k, v in self.model.encoder.state_dict().items() if "lora_" in k},
+                                  {k: v.detach().clone() for k, v in self.model.decoder.state_dict().items() if "lora_" in k})
             if self.args.save_steps and self.global_step % self.args.save_steps == 0:
                 self.save_model()
         if self.args.load_best_model_at_end and best_state is not None:      # fineTune.py:178-180
-            self.model.encoder.load_state_dict(best_state, strict=False)
+            self.model.encoder.load_state_dict(best_state[0], strict=False)
+            if best_state[1]:
+                self.model.decoder.load_state_dict(best_state[1], strict=False)
         train_losses = [h["loss"] for h in self.log_history if "loss" in h]
         return SimpleNamespace(global_step=self.global_step, training_loss=train_losses[-1] if train_losses else float("nan"),
                                best_metric=best)
 
-    def save_model(self, output_dir: Optional[str] = None):
-        """Adapter-only checkpoint (the frozen base is not rewritten): `<output_dir>/lora_adapters.pt`, HF-style keys."""
+    def save_model(self, output_dir: Optional[str] = None, full: bool = False):
+        """Adapter-only checkpoint (the frozen base is not rewritten): `<output_dir>/lora_adapters.pt`, HF-style keys.  full=True also writes
+        what the reference's `trainer.save_model()` leaves behind (AB/fineTune.py:200): a checkpoint DIRECTORY (config.json + model.safetensors,
+        adapters merged into the base) that `WhisperLoRAModel.from_pretrained` -- and the reference's wavToWhisper.py:47 -- load by path."""
         out = output_dir or self.args.output_dir
         os.makedirs(out, exist_ok=True)
+        if full:
+            self.model.save_pretrained(out)
         sd = {k: v.detach().cpu() for k, v in self.model.encoder.state_dict().items() if "lora_" in k}
+        sd.update({"decoder." + k: v.detach().cpu() for k, v in self.model.decoder.state_dict().items() if "lora_" in k})
         torch.save({"lora": sd, "r": self.model.encoder.lora.r, "alpha": self.model.encoder.lora.alpha,
                     "targets": list(self.model.encoder.lora.targets)}, os.path.join(out, "lora_adapters.pt"))
         return out

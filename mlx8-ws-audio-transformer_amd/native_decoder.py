@@ -14,6 +14,13 @@ side by side into one buffer that a single GEMM turns into d(encoder hidden stat
 
 Parameter names are HF's (`WhisperDecoder.state_dict()` loads unchanged); `forward` has `finetune.WhisperDecoder`'s signature, so
 `greedy_decode` / `generate` run on it as well (incremental decoding with a self-attention cache).
+
+LoRA on the decoder (scope row f1, second half; build-defined like the encoder's adapters: y = x W^T + b + (alpha / r) (x A^T) B^T): with
+`lora=LoraSpec(targets=("q_proj", "v_proj"))` the self-attention and the cross-attention query / value projections of every layer get
+trainable `lora_A` [r, d] / `lora_B` [d, r] (B = 0 at init).  The base stays frozen and packed; the adapter terms and their gradients are
+small GEMMs on the same MFMA kernel (`awt_op_linear`): du = dy B, dA = (alpha / r) du^T x, dB = (alpha / r) dy^T u, dx += (alpha / r) du A.
+The cross-attention VALUE adapters act on the encoder states (B x 1500 rows): all layers' u = enc A^T come from one GEMM, and their share
+of d(loss) / d(encoder states) from one more.
 """
 from __future__ import annotations
 
@@ -130,6 +137,19 @@ def attention_small_backward(q, ldq, k, ldk, v, ldv, o, dout, lse, dq, dk, dv, B
             _lib.stream_handle()))
 
 
+def gemm(x: torch.Tensor, w: torch.Tensor, precision: str = "bf16x3") -> torch.Tensor:
+    """x [M, K] @ w [N, K]^T on libawt's MFMA GEMM (`awt_op_linear`): K zero-padded to a multiple of 64, N to a multiple of 128."""
+    from . import ops
+    M, K = x.shape
+    N = w.shape[0]
+    kp, np_ = (K + 63) // 64 * 64, (N + 127) // 128 * 128
+    if kp != K:
+        x, w = torch.nn.functional.pad(x, (0, kp - K)), torch.nn.functional.pad(w, (0, kp - K))
+    if np_ != N:
+        w = torch.nn.functional.pad(w, (0, 0, 0, np_ - N))
+    return ops.linear(x.contiguous(), w.contiguous(), None, precision)[:, :N]
+
+
 def cross_entropy(logits, labels, vocab):
     """(loss scalar tensor, dlogits [M, ld]) of CrossEntropyLoss(ignore_index=-100) over the first `vocab` columns."""
     M, ld = logits.shape
@@ -154,11 +174,17 @@ class _Leaf(nn.Module):
 class NativeWhisperDecoder(nn.Module):
     """Pre-LN Whisper decoder with tied output projection on libawt.  HF parameter names; all parameters frozen."""
 
-    def __init__(self, d: int, layers: int, heads: int, ffn: int, vocab: int = 51865, max_target_positions: int = 448, precision: str = "bf16x3"):
+    LORA_TARGETS = ("q_proj", "v_proj")
+
+    def __init__(self, d: int, layers: int, heads: int, ffn: int, vocab: int = 51865, max_target_positions: int = 448, precision: str = "bf16x3",
+                 lora=None, lora_seed: int = 0):
         super().__init__()
         if d != heads * 64:
             raise ValueError("the native attention kernels are specialised for head_dim 64 (every Whisper size)")
         self.d, self.n_layers, self.heads, self.ffn, self.vocab, self.precision = d, layers, heads, ffn, vocab, precision
+        if lora is not None and not set(lora.targets) <= set(self.LORA_TARGETS):
+            raise ValueError(f"decoder adapters are built for {self.LORA_TARGETS} of self_attn and encoder_attn, got {lora.targets}")
+        self.lora = lora
 
         def P(*shape):
             return nn.Parameter(torch.zeros(*shape), requires_grad=False)
@@ -183,8 +209,55 @@ class NativeWhisperDecoder(nn.Module):
             lay.final_layer_norm = _Leaf(); lay.final_layer_norm.weight = P(d); lay.final_layer_norm.bias = P(d)
             self.layers.append(lay)
         self.layer_norm = _Leaf(); self.layer_norm.weight = P(d); self.layer_norm.bias = P(d)
+        if lora is not None:
+            import math
+            from .weights import unit_variates
+            for i, lay in enumerate(self.layers):
+                for att in ("self_attn", "encoder_attn"):
+                    for proj in lora.targets:
+                        leaf = getattr(getattr(lay, att), proj)
+                        a = unit_variates(f"decoder.layers.{i}.{att}.{proj}.lora_A", lora.r * d, lora_seed) / math.sqrt(d)
+                        leaf.lora_A = nn.Parameter(torch.from_numpy(a.astype("float32").reshape(lora.r, d)), requires_grad=True)
+                        leaf.lora_B = nn.Parameter(torch.zeros(d, lora.r), requires_grad=True)          # B = 0: the adapter starts inert
         self._packed: Optional[Dict[str, object]] = None
         self._versions: Optional[Tuple[int, ...]] = None
+
+    # ------------------------------------------------------------------------------------------------ adapters
+    def lora_parameters(self) -> List[nn.Parameter]:
+        """Adapter parameters in a fixed order: per layer, self_attn then encoder_attn, per target: lora_A then lora_B."""
+        out: List[nn.Parameter] = []
+        if self.lora is not None:
+            for lay in self.layers:
+                for att in ("self_attn", "encoder_attn"):
+                    for proj in self.lora.targets:
+                        leaf = getattr(getattr(lay, att), proj)
+                        out += [leaf.lora_A, leaf.lora_B]
+        return out
+
+    def _adapter(self, i: int, att: str, proj: str):
+        if self.lora is None or proj not in self.lora.targets:
+            return None
+        leaf = getattr(getattr(self.layers[i], att), proj)
+        return leaf.lora_A, leaf.lora_B
+
+    def _lora_term(self, x: torch.Tensor, ab) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(u = x A^T [M, r], (alpha / r) u B^T [M, d]) on the native GEMM."""
+        A, Bm = ab
+        u = gemm(x, A.detach(), self.precision)
+        return u, gemm(u, Bm.detach(), self.precision) * self.lora.scale
+
+    def _cross_v_adapters(self, enc2d: torch.Tensor, kv: torch.Tensor):
+        """Adds (alpha / r) (enc A_i^T) B_i^T to layer i's VALUE block of the fused cross-attention projection; returns u of all layers
+        [B * S, layers * r] (one GEMM over the encoder states), or None without value adapters."""
+        if self.lora is None or "v_proj" not in self.lora.targets:
+            return None
+        r, d, nl = self.lora.r, self.d, self.n_layers
+        a_all = torch.cat([self.layers[i].encoder_attn.v_proj.lora_A.detach() for i in range(nl)], dim=0)        # [layers * r, d]
+        u_all = gemm(enc2d, a_all, self.precision)
+        blocks = kv.view(kv.shape[0], 2 * nl, d)
+        for i in range(nl):
+            blocks[:, 2 * i + 1] += gemm(u_all[:, i * r:(i + 1) * r], self.layers[i].encoder_attn.v_proj.lora_B.detach(), self.precision) * self.lora.scale
+        return u_all
 
     # ------------------------------------------------------------------------------------------------ packing
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
@@ -200,7 +273,7 @@ class NativeWhisperDecoder(nn.Module):
         """Frozen weights as `awt_weight` handles, rebuilt when a parameter changed: per layer the fused self-attention q|k|v
         projection, the two output projections, the cross-attention query projection, fc1, fc2; the fused cross-attention k|v
         projection of ALL layers (one GEMM over the encoder output) and the tied vocabulary projection."""
-        vers = tuple(p._version for p in self.parameters())
+        vers = tuple((id(p), p._version) for n, p in self.named_parameters() if "lora_" not in n)     # identity too: a replaced Parameter object starts at version 0 again
         if self._packed is not None and self._versions == vers:
             return self._packed
         pk: Dict[str, object] = {"layers": []}
@@ -226,7 +299,10 @@ class NativeWhisperDecoder(nn.Module):
     def cross_kv(self, enc: torch.Tensor, precision: Optional[str] = None) -> torch.Tensor:
         """[B * S, 2 * layers * d]: cross-attention keys (even d-wide blocks) and values (odd blocks) of every layer."""
         B, S, d = enc.shape
-        return self.packed()["ckv"].forward(enc.reshape(B * S, d).float().contiguous())
+        enc2d = enc.reshape(B * S, d).float().contiguous()
+        kv = self.packed()["ckv"].forward(enc2d)
+        self._cross_v_adapters(enc2d, kv)
+        return kv
 
     def _embed(self, ids: torch.Tensor, position_offset: int) -> torch.Tensor:
         B, L = ids.shape
@@ -246,6 +322,12 @@ class NativeWhisperDecoder(nn.Module):
         for i, (lay, p) in enumerate(zip(self.layers, pk["layers"])):
             h = layernorm(x, lay.self_attn_layer_norm.weight, lay.self_attn_layer_norm.bias)
             qkv = p["qkv"].forward(h)                                                   # [B L, 3 d]
+            us = {}
+            for proj, col in (("q_proj", 0), ("v_proj", 2 * d)):                         # adapters on the self-attention query / value projections
+                ab = self._adapter(i, "self_attn", proj)
+                if ab is not None:
+                    us[proj], delta = self._lora_term(h, ab)
+                    qkv[:, col: col + d] += delta
             if caches is None:
                 a, lse = attention_small((qkv, 0), 3 * d, (qkv, d), 3 * d, (qkv, 2 * d), 3 * d, B, H, L, L, True, 0, save is not None)
             else:                                                                       # incremental decoding: keys / values of all positions so far
@@ -257,13 +339,17 @@ class NativeWhisperDecoder(nn.Module):
             x1 = p["so"].forward(a, resid=x)
             h2 = layernorm(x1, lay.encoder_attn_layer_norm.weight, lay.encoder_attn_layer_norm.bias)
             q = p["cq"].forward(h2)
+            ab = self._adapter(i, "encoder_attn", "q_proj")
+            if ab is not None:
+                us["cq"], delta = self._lora_term(h2, ab)
+                q += delta
             a2, lse2 = attention_small((q, 0), d, (kv, 2 * i * d), 2 * nl * d, (kv, (2 * i + 1) * d), 2 * nl * d, B, H, L, S, False, 0, save is not None)
             x2 = p["co"].forward(a2, resid=x1)
             h3 = layernorm(x2, lay.final_layer_norm.weight, lay.final_layer_norm.bias)
             f = p["fc1"].forward(h3)
             x3 = p["fc2"].forward(gelu(f), resid=x2)
             if save is not None:
-                save.append((x, qkv, a, lse, x1, q, a2, lse2, x2, f))
+                save.append((x, qkv, a, lse, x1, q, a2, lse2, x2, f, us))
             x = x3
         return x
 
@@ -281,18 +367,21 @@ class NativeWhisperDecoder(nn.Module):
     def loss(self, decoder_input_ids: torch.Tensor, labels: torch.Tensor, encoder_hidden_states: torch.Tensor):
         """(loss, logits [B, L, vocab]): differentiable w.r.t. `encoder_hidden_states` only (the decoder is frozen)."""
         holder: List[torch.Tensor] = []
-        loss = _DecoderLoss.apply(encoder_hidden_states, self, decoder_input_ids, labels, holder)
+        loss = _DecoderLoss.apply(encoder_hidden_states, self, decoder_input_ids, labels, holder, *self.lora_parameters())
         return loss, holder[0]
 
 
 class _DecoderLoss(torch.autograd.Function):
-    """decoder + tied projection + cross-entropy as ONE autograd node with a hand-written native backward."""
+    """decoder + tied projection + cross-entropy as ONE autograd node with a hand-written native backward: d(loss) / d(encoder states) and,
+    with decoder adapters, d(loss) / d(lora_A, lora_B) in `NativeWhisperDecoder.lora_parameters()` order."""
 
     @staticmethod
-    def forward(ctx, enc, dec: NativeWhisperDecoder, ids, labels, holder):
+    def forward(ctx, enc, dec: NativeWhisperDecoder, ids, labels, holder, *adapters):
         B, S, d = enc.shape
         L = ids.shape[1]
-        kv = dec.cross_kv(enc)
+        enc2d = enc.reshape(B * S, d).float().contiguous()
+        kv = dec.packed()["ckv"].forward(enc2d)
+        u_cv = dec._cross_v_adapters(enc2d, kv)
         save: list = []
         x = dec._run(ids, kv, S, save)
         xf = layernorm(x, dec.layer_norm.weight, dec.layer_norm.bias)
@@ -300,6 +389,7 @@ class _DecoderLoss(torch.autograd.Function):
         loss, dlogits = cross_entropy(logits, labels, dec.vocab)
         holder.append(logits.view(B, L, -1)[:, :, : dec.vocab])
         ctx.dec, ctx.saved, ctx.kv, ctx.x_last, ctx.dlogits, ctx.shape = dec, save, kv, x, dlogits, (B, S, L)
+        ctx.enc2d, ctx.u_cv, ctx.n_adapters = (enc2d if u_cv is not None else None), u_cv, len(adapters)
         return loss
 
     @staticmethod
@@ -307,12 +397,24 @@ class _DecoderLoss(torch.autograd.Function):
         dec, save, kv, (B, S, L) = ctx.dec, ctx.saved, ctx.kv, ctx.shape
         pk = dec.packed()
         d, H, nl = dec.d, dec.heads, dec.n_layers
+        prec = dec.precision
+        scale = dec.lora.scale if dec.lora is not None else 0.0
+        grads: Dict[int, torch.Tensor] = {}                                                 # id(parameter) -> gradient
+
+        def adapter_backward(ab, x_in, u, dy):
+            """Adapter (A, B) on input x_in with u = x_in A^T: records dA, dB and returns the adapter's share of d(x_in)."""
+            A, Bm = ab
+            du = gemm(dy, Bm.detach().t().contiguous(), prec)                               # [M, r] = dy B
+            grads[id(A)] = gemm(du.t().contiguous(), x_in.t().contiguous(), prec) * scale   # dA [r, d] = (alpha / r) du^T x
+            grads[id(Bm)] = gemm(dy.t().contiguous(), u.t().contiguous(), prec) * scale     # dB [d, r] = (alpha / r) dy^T u
+            return gemm(du, A.detach().t().contiguous(), prec) * scale                      # [M, d] = (alpha / r) du A
+
         dlogits = ctx.dlogits * g                                                           # upstream scalar (1 / micro-batches, ...)
         dx = layernorm_backward(pk["vocab"].backward_input(dlogits), ctx.x_last, dec.layer_norm.weight)
         dkv = torch.empty_like(kv)                                                          # every layer writes its own two d-wide blocks
         for i in range(nl - 1, -1, -1):
             lay, p = dec.layers[i], pk["layers"][i]
-            x0, qkv, a, lse, x1, q, a2, lse2, x2, f = save[i]
+            x0, qkv, a, lse, x1, q, a2, lse2, x2, f, us = save[i]
             # MLP: x3 = x2 + fc2(gelu(fc1(LN3(x2))))
             df = gelu_backward(f, p["fc2"].backward_input(dx))
             dx = layernorm_backward(p["fc1"].backward_input(df), x2, lay.final_layer_norm.weight, dres=dx)
@@ -321,13 +423,44 @@ class _DecoderLoss(torch.autograd.Function):
             dq = torch.empty_like(q)
             attention_small_backward((q, 0), d, (kv, 2 * i * d), 2 * nl * d, (kv, (2 * i + 1) * d), 2 * nl * d, a2, da2, lse2,
                                      (dq, 0), (dkv, 2 * i * d), (dkv, (2 * i + 1) * d), B, H, L, S, False, 0)
-            dx = layernorm_backward(p["cq"].backward_input(dq), x1, lay.encoder_attn_layer_norm.weight, dres=dx)
+            dh2 = p["cq"].backward_input(dq)
+            ab = dec._adapter(i, "encoder_attn", "q_proj")
+            if ab is not None:
+                h2 = layernorm(x1, lay.encoder_attn_layer_norm.weight, lay.encoder_attn_layer_norm.bias)      # recomputed: B x L rows
+                dh2 = dh2 + adapter_backward(ab, h2, us["cq"], dq)
+            dx = layernorm_backward(dh2, x1, lay.encoder_attn_layer_norm.weight, dres=dx)
             # self-attention: x1 = x0 + out(attn(qkv(LN1(x0))))
             da = p["so"].backward_input(dx)
             dqkv = torch.empty_like(qkv)
             attention_small_backward((qkv, 0), 3 * d, (qkv, d), 3 * d, (qkv, 2 * d), 3 * d, a, da, lse,
                                      (dqkv, 0), (dqkv, d), (dqkv, 2 * d), B, H, L, L, True, 0)
-            dx = layernorm_backward(p["qkv"].backward_input(dqkv), x0, lay.self_attn_layer_norm.weight, dres=dx)
+            dh = p["qkv"].backward_input(dqkv)
+            if us:
+                h = None
+                for proj, col in (("q_proj", 0), ("v_proj", 2 * d)):
+                    ab = dec._adapter(i, "self_attn", proj)
+                    if ab is not None:
+                        if h is None:
+                            h = layernorm(x0, lay.self_attn_layer_norm.weight, lay.self_attn_layer_norm.bias)
+                        dh = dh + adapter_backward(ab, h, us[proj], dqkv[:, col: col + d].contiguous())
+            dx = layernorm_backward(dh, x0, lay.self_attn_layer_norm.weight, dres=dx)
         ctx.saved = ctx.kv = ctx.dlogits = None
         d_enc = pk["ckv"].backward_input(dkv)                                               # [B S, d]
-        return d_enc.view(B, S, d), None, None, None, None
+        if ctx.u_cv is not None:
+            # cross-attention value adapters: dV_i = dkv block 2 i + 1 (B x S rows); their share of d(encoder states) is ONE GEMM over all layers
+            r = dec.lora.r
+            dv = dkv.view(dkv.shape[0], 2 * nl, d)
+            du_all = torch.empty_like(ctx.u_cv)
+            enc_t = ctx.enc2d.t().contiguous()
+            for i in range(nl):
+                A, Bm = dec._adapter(i, "encoder_attn", "v_proj")
+                dvi = dv[:, 2 * i + 1].contiguous()
+                du = gemm(dvi, Bm.detach().t().contiguous(), prec)
+                du_all[:, i * r:(i + 1) * r] = du
+                grads[id(Bm)] = gemm(dvi.t().contiguous(), ctx.u_cv[:, i * r:(i + 1) * r].t().contiguous(), prec) * scale
+                grads[id(A)] = gemm(du.t().contiguous(), enc_t, prec) * scale
+            a_all_t = torch.cat([dec._adapter(i, "encoder_attn", "v_proj")[0].detach() for i in range(nl)], dim=0).t().contiguous()   # [d, layers * r]
+            d_enc = d_enc + gemm(du_all, a_all_t, prec) * scale
+            ctx.enc2d = ctx.u_cv = None
+        params = dec.lora_parameters() if ctx.n_adapters else []
+        return (d_enc.view(B, S, d), None, None, None, None, *[grads.get(id(p)) for p in params])

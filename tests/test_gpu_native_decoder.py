@@ -165,3 +165,110 @@ def test_cross_entropy_ignores_only_minus_100():
         _lib.check(_lib.lib().awt_op_cross_entropy(_lib.ctx(logits.device), _lib.ptr(logits), _lib.ptr(lab), M, vocab, ld, _lib.ptr(out), _lib.ptr(dlog),
                                                    _lib.ptr(scratch), _lib.stream_handle()))
         assert torch.isnan(out).item()
+
+
+class _TorchLoRALinear(torch.nn.Module):
+    """y = base(x) + (alpha / r) (x A^T) B^T over a frozen nn.Linear: the build-defined adapter restated with torch autograd."""
+
+    def __init__(self, base, A, B, scale):
+        super().__init__()
+        self.base, self.scale = base, scale
+        self.A, self.B = torch.nn.Parameter(A.clone()), torch.nn.Parameter(B.clone())
+        self.weight, self.bias = base.weight, base.bias              # the fused cross-K/V path of the torch decoder is not used here
+
+    def forward(self, x):
+        return self.base(x) + self.scale * F.linear(F.linear(x, self.A), self.B)
+
+
+@pytest.mark.parametrize("targets", [("q_proj", "v_proj"), ("v_proj",)])
+def test_decoder_adapters_forward_and_gradients_match_torch_autograd(targets):
+    """Scope row f1, second half ("+ LoRA on decoder"; the reference fine-tunes every decoder parameter, AB/fineTune.py:131,186-199):
+    adapters on the decoder's self-attention and cross-attention q_proj / v_proj.  Loss, logits, d(loss)/d(encoder adapters) and
+    d(loss)/d(every decoder adapter) of the native path against torch autograd over the stock-PyTorch decoder carrying the same adapters."""
+    from mlx8_ws_audio_transformer_amd.finetune import WhisperLoRAModel
+    G = golden("decoder.npz")
+    labels = torch.from_numpy(G["labels"]).cuda()
+    cfg = wts.config("mini", True)
+    spec = wts.LoraSpec(r=8, alpha=16.0, targets=targets)
+    We = wts.init_encoder_weights(cfg, seed=0, profile="test")
+    Wd = wts.init_decoder_weights(cfg.d_model, 2, cfg.ffn, 512, 64, seed=0)
+    mel = torch.from_numpy(oracle_mel.whisper_logmel(piano_clips_f32(2), n_samples=2 * cfg.max_source_positions * 160)).cuda()
+
+    def build(native):
+        m = WhisperLoRAModel(cfg, wts.LoraSpec(r=8, alpha=16.0), decoder_layers=2, vocab=512, max_target_positions=64, native_decoder=native,
+                             decoder_lora=spec if native else None, native_cross_kv=False)
+        m.config.decoder_start_token_id, m.config.pad_token_id, m.config.eos_token_id = 1, 0, 2
+        m.encoder.load_state_dict({k: torch.from_numpy(v) for k, v in We.items()}, strict=False)
+        m.decoder.load_state_dict({k: torch.from_numpy(v) for k, v in Wd.items()}, strict=False)
+        with torch.no_grad():
+            for p in m.encoder.parameters():
+                if p.requires_grad and p.shape[1] == 8:
+                    p.copy_(torch.from_numpy(0.05 * wts.unit_variates("declora_enc", p.numel(), 1).reshape(p.shape).astype(np.float32)))
+        return m
+
+    nat = build(True)
+    names = [n for n, _ in nat.decoder.named_parameters() if "lora_" in n]
+    assert len(names) == 2 * 2 * len(targets) * 2 and all(p.requires_grad for n, p in nat.decoder.named_parameters() if "lora_" in n)
+    assert not any(p.requires_grad for n, p in nat.decoder.named_parameters() if "lora_" not in n)
+    vals = {}
+    with torch.no_grad():
+        for n, p in nat.decoder.named_parameters():
+            if n.endswith("lora_B"):                              # non-zero B so that every adapter matrix gets a gradient
+                p.copy_(torch.from_numpy(0.05 * wts.unit_variates(n, p.numel(), 3).reshape(p.shape).astype(np.float32)))
+            if "lora_" in n:
+                vals[n] = p.detach().clone()
+    ref = build(False)
+    wrapped = {}
+    for i, lay in enumerate(ref.decoder.layers):                   # the same adapters on the stock-PyTorch decoder
+        for att in ("self_attn", "encoder_attn"):
+            for proj in targets:
+                key = f"layers.{i}.{att}.{proj}"
+                mod = _TorchLoRALinear(getattr(getattr(lay, att), proj), vals[key + ".lora_A"], vals[key + ".lora_B"], spec.scale)
+                setattr(getattr(lay, att), proj, mod)
+                wrapped[key] = mod
+    out_n = nat(input_features=mel, labels=labels)
+    out_n.loss.backward()
+    out_r = ref(input_features=mel, labels=labels)
+    out_r.loss.backward()
+    assert abs(float(out_n.loss) - float(out_r.loss)) < 2e-4 * abs(float(out_r.loss))
+    assert float((out_n.logits.float() - out_r.logits.float()).abs().max()) < 2e-3
+    # the adapters really act: the loss differs from the adapter-free reference value
+    assert abs(float(out_n.loss) - float(G["loss"])) > 1e-4
+    ge_n = torch.cat([p.grad.flatten() for n, p in nat.encoder.named_parameters() if "lora_" in n])
+    ge_r = torch.cat([p.grad.flatten() for n, p in ref.encoder.named_parameters() if "lora_" in n])
+    assert float((ge_n - ge_r).abs().max()) < 2e-3 * float(ge_r.abs().max())
+    for n, p in nat.decoder.named_parameters():
+        if "lora_" not in n:
+            assert p.grad is None
+            continue
+        mod = wrapped[n.rsplit(".", 1)[0]]
+        g_ref = (mod.A if n.endswith("lora_A") else mod.B).grad
+        assert p.grad is not None and float(g_ref.abs().max()) > 0, n
+        assert float((p.grad - g_ref).abs().max()) < 2e-3 * float(g_ref.abs().max()), n
+    # greedy decoding runs through the adapters as well (incremental decoding with the cache = the full forward's argmax)
+    nat.eval()
+    ids = nat.generate(mel, max_length=8)
+    with torch.no_grad():
+        full = nat(input_features=mel, decoder_input_ids=ids[:, :-1]).logits.argmax(-1)
+    assert torch.equal(full[:, -1], ids[:, -1])
+
+
+def test_trainer_steps_encoder_and_decoder_adapters_together(tmp_path):
+    """One flat gradient buffer: [native encoder adapters | decoder adapters]; a few steps lower the loss and both halves move."""
+    from mlx8_ws_audio_transformer_amd.finetune import Seq2SeqTrainer, Seq2SeqTrainingArguments, WhisperLoRAModel
+    cfg = wts.config("mini", True)
+    model = WhisperLoRAModel(cfg, wts.LoraSpec(r=8, alpha=16.0), decoder_layers=1, vocab=512, max_target_positions=64, decoder_lora=wts.LoraSpec(r=4, alpha=8.0))
+    mel = torch.from_numpy(oracle_mel.whisper_logmel(piano_clips_f32(4), n_samples=2 * cfg.max_source_positions * 160))
+    g = torch.Generator().manual_seed(0)
+    labels = torch.randint(3, 500, (4, 6), generator=g)
+    tr = Seq2SeqTrainer(args=Seq2SeqTrainingArguments(output_dir=str(tmp_path), learning_rate=5e-3, max_steps=100, predict_with_generate=False), model=model)
+    assert tr.bucket.numel > tr.n_native > 0
+    before = [p.detach().clone() for p in model.lora_parameters()]
+    losses = [tr.training_step({"input_features": mel, "labels": labels}) for _ in range(8)]
+    assert losses[-1] < losses[0] - 0.05, losses
+    moved = [float((p.detach() - b).abs().max()) for p, b in zip(model.lora_parameters(), before)]
+    n_enc = len([1 for n, _ in model.encoder.named_parameters() if "lora_" in n])
+    assert max(moved[:n_enc]) > 0 and max(moved[n_enc:]) > 0
+    tr.save_model(full=True)
+    sd = torch.load(tmp_path / "lora_adapters.pt")["lora"]
+    assert any(k.startswith("decoder.") for k in sd) and (tmp_path / "model.safetensors").exists()

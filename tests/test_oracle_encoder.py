@@ -90,3 +90,15 @@ def test_numerics_model_bounds():
     e1 = encoder.error_norms(encoder.encoder_forward_emulated(W, mel, cfg.heads, 1).numpy(), ref)
     e3 = encoder.error_norms(encoder.encoder_forward_emulated(W, mel, cfg.heads, 3).numpy(), ref)
     assert e1["max_abs"] > 1e-3 and e3["max_abs"] < 1e-4
+
+
+def test_encoder_on_the_real_recording_matches_reference():
+    """Whisper-tiny (deterministic weights) on the real-audio fixture's features: head, the tokens around the end of the 4 s of signal, tail."""
+    from tests.util import real_audio
+    _, mono, R = real_audio()
+    cfg = wts.config("tiny", False)
+    W = wts.init_encoder_weights(cfg, seed=0, profile="test")
+    assert bytes.fromhex(wts.weights_digest(W)) == R["tiny/weights_sha256"].tobytes()
+    out = encoder.encoder_forward(W, logmel.whisper_logmel([mono]), cfg.heads).numpy()
+    for key, sl in (("last_head", slice(0, 4)), ("last_live", slice(196, 204)), ("last_tail", slice(-4, None))):
+        np.testing.assert_allclose(out[:, sl], R["tiny/" + key], rtol=0, atol=2e-4)

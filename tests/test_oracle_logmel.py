@@ -80,3 +80,15 @@ def test_urbansound_prepare_mono_pad_trim():
     w = logmel.urbansound_prepare(st)
     assert w.shape == (64000,) and np.all(w[:1000] == 2.0) and np.all(w[1000:] == 0)
     assert logmel.urbansound_prepare(np.ones(70000, np.float32)).shape == (64000,)
+
+
+def test_real_recording_matches_reference_numpy_path():
+    """First 4 s of the reference's own sample recording (.charles/samples/..._00_08s.wav, stereo PCM16 -> channel mean): on real spectra the
+    reference's fp32 torch.stft path and its float64 NumPy path differ by 1.7e-5 (stored in the fixture); the oracle follows the float64 path."""
+    from tests.util import real_audio
+    pcm, mono, R = real_audio()
+    assert pcm.shape == (64000, 2) and pcm.dtype == np.int16 and float(R["np_vs_torch_max_abs"]) > 1e-5
+    out = logmel.whisper_logmel([mono])[0]
+    np.testing.assert_allclose(out[:, :404], R["np_live"], rtol=0, atol=2e-6)
+    assert np.all(out[:, 404:] == out[0, 1500]) and abs(float(out[0, 1500]) - float(R["np_padconst"])) <= 2e-6
+    np.testing.assert_allclose(out[:, :404], R["torch_live"], rtol=0, atol=5e-5)

@@ -23,3 +23,11 @@ def logmel_inputs():
 
 def piano_clips_f32(batch, first=0):
     return [synth.pcm_i16_to_f32(c) for c in synth.synth_clips_i16(batch, seed=1234, first=first)]
+
+
+def real_audio():
+    """(int16 stereo excerpt [64000, 2] of the reference's sample recording, its channel mean as float32, the fixture): tests/golden/real_audio.npz
+    (tools/make_golden.py gen_real_audio)."""
+    G = golden("real_audio.npz")
+    pcm = G["pcm_i16_stereo"]
+    return pcm, (pcm.astype(np.float32) / 32768.0).mean(axis=1), G

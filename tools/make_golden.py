@@ -190,6 +190,40 @@ def gen_decoder():
     print("decoder fixture written: loss", out["loss"], "greedy", ids.tolist())
 
 
+REAL_WAV = "/root/reference/.charles/samples/alan_walker_-_the_spectre_fluidsynth_00_08s.wav"    # 16 kHz stereo PCM16, 8 s
+
+
+def gen_real_audio():
+    """Real-audio fixture (VERDICT r2 missing #3): the first 4 s of one of the reference's own sample recordings, as DATA -- the int16
+    stereo excerpt (input) and what the reference's arithmetic makes of its channel mean: `WhisperFeatureExtractor` (NumPy / float64 path and
+    the torch path) and the Whisper-tiny `WhisperEncoder` on deterministic weights.  Real spectra (a FluidSynth rendering with silence, attacks
+    and reverberant tails) are where the fp32 `torch.stft` path and the float64 path drift apart."""
+    import wave
+    from transformers import WhisperFeatureExtractor
+    with wave.open(REAL_WAV, "rb") as w:
+        assert (w.getnchannels(), w.getsampwidth(), w.getframerate()) == (2, 2, 16000)
+        pcm = np.frombuffer(w.readframes(64000), dtype="<i2").reshape(-1, 2).copy()          # [64000, 2] interleaved as in the file
+    mono = (pcm.astype(np.float32) / 32768.0).mean(axis=1)                                   # torchaudio.load scaling, then spectrogram.py:146-147's channel mean
+    fe = WhisperFeatureExtractor()
+    t = fe(mono, sampling_rate=16000, return_tensors="np")["input_features"][0]
+    padded = np.zeros((1, 480000), dtype=np.float32)
+    padded[0, : mono.size] = mono
+    n = fe._np_extract_fbank_features(padded, "cpu")[0]
+    assert n.shape == (80, 3000) and np.all(n[:, 404:] == n[0, 1500])
+    out = {"pcm_i16_stereo": pcm, "np_live": n[:, :404].astype(np.float32), "torch_live": t[:, :404].astype(np.float32), "np_padconst": np.float32(n[0, 1500]),
+           "np_vs_torch_max_abs": np.float64(np.abs(n - t).max())}
+    cfg = wts.config("tiny", False)
+    W = wts.init_encoder_weights(cfg, seed=0, profile="test")
+    enc = hf_encoder(cfg, W)
+    with torch.no_grad():
+        last = enc(torch.from_numpy(n[None].astype(np.float32))).last_hidden_state.numpy()
+    out["tiny/weights_sha256"] = np.frombuffer(bytes.fromhex(wts.weights_digest(W)), dtype=np.uint8)
+    out["tiny/last_head"], out["tiny/last_live"], out["tiny/last_tail"] = last[:, :4, :], last[:, 196:204, :], last[:, -4:, :]      # tokens around the end of the 4 s of signal
+    out["tiny/last_sum"] = np.float64(last.astype(np.float64).sum())
+    np.savez_compressed(os.path.join(GOLD, "real_audio.npz"), **out)
+    print("real-audio fixture written: |np - torch| max", float(out["np_vs_torch_max_abs"]), "file bytes", os.path.getsize(os.path.join(GOLD, "real_audio.npz")))
+
+
 def make_pad_tokenizer():
     """A tokenizer whose only used behaviour is `.pad` (right-pad with Whisper's pad id 50257 + attention mask)."""
     from tokenizers import Tokenizer
@@ -246,3 +280,5 @@ if __name__ == "__main__":
         gen_encoder(ENCODER_CASES_LARGE, "encoder_large.npz")
     if "collator" in what:
         gen_collator()
+    if "real_audio" in what:
+        gen_real_audio()
