@@ -280,13 +280,52 @@ def noop_main(a):
     R.finish()
 
 
+def finetune_cpu_baseline(a, torch, cfg, labels_all):
+    """The fine-tune step's CPU baseline: the oracle encoder (with the LoRA term) + the stock-PyTorch restatement of the decoder / loss
+    (finetune.WhisperDecoder, pinned to WhisperForConditionalGeneration by tests/golden/decoder.npz) under torch autograd, forward + backward
+    to the adapters, on 2 of the step's clips (1 warm-up + 2 timed passes, median) on this process' CPU share (cpu_budget())."""
+    import numpy as np
+    import torch.nn.functional as F
+    from mlx8_ws_audio_transformer_amd import synth, weights as wts
+    from mlx8_ws_audio_transformer_amd.finetune import WhisperDecoder, shift_tokens_right, DECODER_START, PAD_ID
+    from oracle import encoder as oenc, logmel as omel
+    threads, note = cpu_budget()
+    torch.set_num_threads(threads)
+    n = 2
+    spec = wts.LoraSpec(r=a.lora_r, alpha=16.0)
+    W = wts.init_encoder_weights(cfg, 0, "hf")
+    lora = {k: torch.from_numpy(v).requires_grad_(True) for k, v in wts.init_lora_weights(cfg, spec, 0, zero_b=False).items()}
+    torch.manual_seed(0)
+    dec = WhisperDecoder(cfg.d_model, cfg.layers, cfg.heads, cfg.ffn)
+    for p_ in dec.parameters():
+        p_.requires_grad = False
+    clips = [synth.pcm_i16_to_f32(c) for c in synth.synth_clips_i16(n, seed=1234, first=0)]
+    labels = labels_all[:n].clone()
+    times = []
+    for it in range(3):
+        t0 = time.perf_counter()
+        mel = omel.whisper_logmel(clips, n_samples=cfg.n_frames * 160)
+        hidden = oenc.encoder_forward({**{k: torch.from_numpy(v) for k, v in W.items()}, **lora}, mel, cfg.heads, lora_scale=spec.scale)
+        logits = dec(shift_tokens_right(labels, PAD_ID, DECODER_START), hidden)
+        loss = F.cross_entropy(logits.view(-1, logits.shape[-1]), labels.reshape(-1), ignore_index=-100)
+        for v in lora.values():
+            v.grad = None
+        loss.backward()
+        if it:
+            times.append(time.perf_counter() - t0)
+    m = sorted(times)[len(times) // 2]
+    return {"value": round(n / m, 3), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d of the step's clips: oracle log-mel + encoder with LoRA r=%d + torch decoder + CE, forward and backward under autograd (no optimizer); "
+                      "1 warm-up + 2 timed passes, median %.2f s per pass" % (n, a.lora_r, m), "threads_note": note}
+
+
 def finetune_main(a):
     """BASELINE.json configs[2]/[3]: Whisper-small + LoRA (q_proj, v_proj) fine-tune step, B clips per GPU, 12 label tokens,
     one in-place mean all-reduce of the flat adapter-gradient buffer per step (RCCL through libawt's communicator under the
-    nccl backend).  Decoder + CE are stock PyTorch ops (scope row 'next')."""
+    nccl backend).  Encoder forward / backward, decoder and loss are libawt kernels; AdamW on the adapters is torch.optim."""
     R = Ranks(a)
     torch, dev, rank, world = R.torch, R.dev, R.rank, R.world
-    from mlx8_ws_audio_transformer_amd import synth, weights as wts
+    from mlx8_ws_audio_transformer_amd import _lib, synth, weights as wts
     from mlx8_ws_audio_transformer_amd.feature_extraction import logmel_whisper_device
     from mlx8_ws_audio_transformer_amd.finetune import Seq2SeqTrainer, Seq2SeqTrainingArguments, WhisperLoRAModel
     cfg = wts.config(a.model, a.trimmed)
@@ -307,20 +346,55 @@ def finetune_main(a):
 
     for _ in range(a.warmup):
         step()
+    # the dominant kernel class (every GEMM of the step: encoder forward + backward, adapters, decoder) is event-timed live in the timed
+    # region; the attention classes' shares come from one extra untimed step
+    _lib.prof_enable(True, ["gemm"])
+    for k in _lib.PROF_CLASSES:
+        _lib.prof_collect(k)
     dt, mine, _ = R.timed(step, a.steps)
+    gemm_ms, gemm_n, gemm_flop = _lib.prof_collect("gemm")
+    _lib.prof_enable(True, [k for k in _lib.PROF_CLASSES if k != "gemm"])
+    step()
+    shares = {"gemm": round(gemm_ms / a.steps, 3)}
+    other = {}
+    for k in _lib.PROF_CLASSES:
+        if k != "gemm":
+            other[k] = _lib.prof_collect(k)
+            shares[k] = round(other[k][0], 3)
+    _lib.prof_enable(False)
     rates = R.gather(B * a.steps / mine)
     if rank == 0:
-        print(json.dumps({
+        achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        terms = float(_lib.MFMA_PER_PAIR[a.precision])
+        bwd_ms, bwd_n, bwd_flop = other.get("attention_bwd", (0.0, 0, 0.0))
+        result = {
             "metric": "4s@16kHz clips/sec through mel+Whisper-%s LoRA fine-tune step" % a.model, "value": round(B * world * a.steps / dt, 2),
             "unit": "clips/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": arithmetic_dtype(a.precision), "data": "synthetic",
+            "device": device_info(torch, dev),
             "config": {"workload": "LoRA r=%d (q_proj, v_proj) fine-tune step: log-mel + encoder fwd/bwd (HIP) + decoder/CE (%s) + gradient exchange + AdamW" % (
                            a.lora_r, "torch" if a.torch_decoder else "HIP"),
                        "clips_per_gpu_per_step": B, "global_batch": B * world, "precision": a.precision, "label_tokens": 12, "decoder_dtype": a.decoder_dtype,
                        "backward_precision": a.backward_precision or a.precision,
+                       "weights": "seed-0 random init, arbitrary fp32 values (SURVEY.md 8(d) C3); adapters A ~ N(0, 1/d), B = 0",
                        "adapter_grad_elems": tr.bucket.numel, "gradient_exchange": tr.exchange,
                        "parallelism": "dp%d, one in-place mean all-reduce of %.2f MB per step" % (world, tr.bucket.numel * 4 / 1e6)},
-            "ranks": R.describe(rates), "last_loss": state["loss"]}))
+            "roofline": {"bound": "mfma", "kernel": "gemm_kernel<%s> (every GEMM of the step: encoder forward and backward, adapter terms, decoder)" % a.precision,
+                         "achieved": round(achieved, 2), "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_DENSE_TFLOPS, 4),
+                         "traffic": None, "launches": gemm_n, "avg_launch_ms": round(gemm_ms / max(gemm_n, 1), 4),
+                         "mfma_issue_frac": round(terms * achieved / PEAK_BF16_DENSE_TFLOPS, 4),
+                         "note": "algorithmic FLOP = 2 M N K per launch; HIP events on the launch stream inside the timed region"},
+            "roofline_attention_backward": {
+                "bound": "mfma", "kernel": "attention_bwd_kernel (dq launch + dk/dv launch per layer)",
+                "achieved": round(bwd_flop * (10.0 / 14.0) / (bwd_ms * 1e-3) / 1e12, 2) if bwd_ms > 0 else None, "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(bwd_flop * (10.0 / 14.0) / (bwd_ms * 1e-3) / 1e12 / PEAK_BF16_DENSE_TFLOPS, 4) if bwd_ms > 0 else None,
+                "launches": bwd_n, "ms_per_step": round(bwd_ms, 3),
+                "note": "algorithmic FLOP = five S x S x 64 products per head (s, dv, dp, dq, dk) = 10 B H S^2 64; the two launches form s and dp twice (seven products)"},
+            "time_share_ms_per_step": shares,
+            "ranks": R.describe(rates), "last_loss": state["loss"], "build": source_hash()}
+        if world == 1 and not a.no_cpu_baseline:
+            result["cpu_baseline"] = finetune_cpu_baseline(a, torch, cfg, labels)
+        print(json.dumps(result))
     R.finish()
 
 

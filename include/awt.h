@@ -296,7 +296,8 @@ int awt_tuning_set(const char* key, int value);
  * awt_prof_collect synchronises the events and returns accumulated milliseconds and launch count
  * for one class, then resets that class. */
 enum { AWT_PROF_LOGMEL = 0, AWT_PROF_GEMM = 1, AWT_PROF_ATTENTION = 2, AWT_PROF_LAYERNORM = 3, AWT_PROF_OTHER = 4,
-       AWT_PROF_NCLASSES = 5 };
+       AWT_PROF_ATTENTION_BWD = 5,     /* the attention backward launches (fine-tune step), apart from the forward kernel */
+       AWT_PROF_NCLASSES = 6 };
 int awt_prof_enable(awt_ctx* c, int mask);
 int awt_prof_collect(awt_ctx* c, int klass, double* total_ms, int64_t* launches, double* flops);
 

@@ -35,7 +35,7 @@ MFMA_PER_PAIR = {"bf16": 1, "bf16x3": 3, "fp16x3": 3, "f16f8": 2}   # MFMA-equiv
 BWD_ACCUMULATE, BWD_ALLREDUCE = 1, 2
 COMM_ID_BYTES = 128
 LORA_BITS = {"q_proj": 1, "k_proj": 2, "v_proj": 4, "out_proj": 8, "fc1": 16, "fc2": 32}
-PROF_CLASSES = {"logmel": 0, "gemm": 1, "attention": 2, "layernorm": 3, "other": 4}
+PROF_CLASSES = {"logmel": 0, "gemm": 1, "attention": 2, "layernorm": 3, "other": 4, "attention_bwd": 5}
 
 _vp, _i, _i64, _sz, _f = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_float
 _SIGNATURES = {

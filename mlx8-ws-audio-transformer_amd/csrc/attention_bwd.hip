@@ -301,7 +301,7 @@ int launch_attention_bwd(awt_ctx* c, const bf16_t* q_hi, const bf16_t* q_lo, con
   AWT_REQUIRE(terms == 1 || terms == 3, AWT_ERR_INVALID, "attention_bwd: terms must be 1 or 3");
   AWT_REQUIRE(q_hi && k_hi && v_hi && o_hi && do_hi && lse2 && delta && g_hi, AWT_ERR_INVALID, "attention_bwd: null argument");
   AWT_REQUIRE(terms == 1 || (q_lo && k_lo && v_lo && o_lo && do_lo && g_lo), AWT_ERR_INVALID, "attention_bwd: lo planes required");
-  ProfScope prof(c, AWT_PROF_ATTENTION, s, 14.0 * (double)B * H * (double)S * S * 64);   // 7 products (s and dp are formed twice)
+  ProfScope prof(c, AWT_PROF_ATTENTION_BWD, s, 14.0 * (double)B * H * (double)S * S * 64);   // 7 products (s and dp are formed twice)
   const int64_t n8 = (int64_t)B * S * H * 64 / 8;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, do_hi, terms == 3 ? do_lo : nullptr, o_hi,
                      terms == 3 ? o_lo : nullptr, delta, B, H, S);

@@ -19,7 +19,7 @@ struct awt_prof_state {
   struct Span { hipEvent_t a, b; };
   std::vector<Span> spans[AWT_PROF_NCLASSES];
   std::vector<Span> pool;
-  double flops[AWT_PROF_NCLASSES] = {0, 0, 0, 0, 0};
+  double flops[AWT_PROF_NCLASSES] = {};
   Span open[AWT_PROF_NCLASSES];
 };
 

@@ -219,7 +219,7 @@ def test_transcribe_from_a_checkpoint_directory(tmp_path):
     from mlx8_ws_audio_transformer_amd.finetune import WhisperLoRAModel
     from mlx8_ws_audio_transformer_amd.transcribe import NoteTokenizer, transcribe_audio_FT
     tok = NoteTokenizer()
-    cfg = wts.config("mini", True)
+    cfg = wts.config("mini", False)              # the processor pads to 30 s: 3000 frames -> 1500 positions
     We = {k: torch.from_numpy(v) for k, v in wts.init_encoder_weights(cfg, 0, "test").items()}
     Wd = {k: torch.from_numpy(v) for k, v in wts.init_decoder_weights(cfg.d_model, 1, cfg.ffn, tok.vocab_size, 64, 0).items()}
     hf = {"d_model": cfg.d_model, "encoder_layers": cfg.layers, "encoder_attention_heads": cfg.heads, "encoder_ffn_dim": cfg.ffn, "decoder_layers": 1,

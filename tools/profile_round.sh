@@ -1,18 +1,20 @@
 #!/bin/bash
 # Round profile of the default bench workload: kernel-trace stats + HBM traffic counters (separate PMC passes).
-# Usage (GPU box): bash tools/profile_round.sh r01
+# Usage (GPU box): bash tools/profile_round.sh <tag> <precision> <weights: fp32 | fp16>
+# (bench.py starts no helper process of any kind under a profiler: its power sampler is a thread and stays off when rocprofv3's preload is present)
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
-tag=${1:-r02}
-prec=${2:-bf16x3}
+tag=${1:-r03}
+prec=${2:-f16f8}
+wts=${3:-fp32}
 out=gpurun_out/prof_$tag; rm -rf $out; mkdir -p $out
-args="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fast-mode --no-power --precision $prec"
+args="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fast-mode --no-power --precision $prec --weights $wts"
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $args > $out/trace.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc_$c -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-fast-mode --no-power --precision $prec > $out/pmc_$c.log 2>&1
+  timeout -k 10 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc_$c -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-fast-mode --no-power --precision $prec --weights $wts > $out/pmc_$c.log 2>&1
 done
 # MFMA utilisation and effective clock (own pass; SQ + GRBM slots)
-timeout -k 10 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_MFMA -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-fast-mode --no-power --precision $prec > $out/pmc_MFMA.log 2>&1
-python3 - $out $tag $prec <<'PY2'
+timeout -k 10 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_MFMA -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-fast-mode --no-power --precision $prec --weights $wts > $out/pmc_MFMA.log 2>&1
+python3 - $out $tag $prec $wts <<'PY2'
 import csv, glob, json, sys, collections
 out, tag = sys.argv[1], sys.argv[2]
 sys.path.insert(0, "."); import bench
@@ -40,11 +42,11 @@ if cc and kt:
                   "wave_cycles_wait_any_frac": d["SQ_WAIT_ANY"] / d["SQ_WAVE_CYCLES"] if d["SQ_WAVE_CYCLES"] else None,
                   "wave_cycles_wait_inst_frac": d["SQ_WAIT_INST_ANY"] / d["SQ_WAVE_CYCLES"] if d["SQ_WAVE_CYCLES"] else None,
                   "wave_cycles_active_frac": d["SQ_ACTIVE_INST_ANY"] / d["SQ_WAVE_CYCLES"] if d["SQ_WAVE_CYCLES"] else None}
-    json.dump({"tag": tag, "build": bench.source_hash(), "precision": sys.argv[3], "note": "profiled pass (clocks read ~2-3 % lower than un-profiled); mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)",
+    json.dump({"tag": tag, "build": bench.source_hash(), "precision": sys.argv[3], "weights": sys.argv[4], "note": "profiled pass (clocks read ~2-3 % lower than un-profiled); mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)",
                "per_kernel": res}, open(f"{out}/mfma.json", "w"), indent=1)
     print(json.dumps(res, indent=1))
 PY2
-python3 - $out $tag $prec <<'PY'
+python3 - $out $tag $prec $wts <<'PY'
 import csv, glob, json, sys, collections
 out, tag = sys.argv[1], sys.argv[2]
 sys.path.insert(0, "."); import bench
@@ -72,7 +74,7 @@ for k, d in res.items():
     summary[k] = {"launches_counted": n, "fetch_bytes_per_launch_corrected": fetch_kb * 1024 * 2 / max(n, 1),
                   "write_bytes_per_launch": write_kb * 1024 / max(n, 1),
                   "hbm_bytes_per_launch": (fetch_kb * 2 + write_kb) * 1024 / max(n, 1)}
-json.dump({"tag": tag, "build": bench.source_hash(), "precision": sys.argv[3], "workload": "bench.py default (Whisper-small, parity, B=64, %s)" % sys.argv[3], "per_kernel": summary,
+json.dump({"tag": tag, "build": bench.source_hash(), "precision": sys.argv[3], "weights": sys.argv[4], "workload": "bench.py default (Whisper-small, parity, B=64, %s, %s weights)" % (sys.argv[3], sys.argv[4]), "per_kernel": summary,
            "note": "FETCH_SIZE x2 per the gfx950 correction; counters from separate --pmc passes"}, open(f"{out}/traffic.json", "w"), indent=1)
 print(json.dumps(summary, indent=1))
 PY
