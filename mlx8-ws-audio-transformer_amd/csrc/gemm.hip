@@ -492,7 +492,11 @@ template <int N> __device__ __forceinline__ void wait_vm(bf16x8& f0, bf16x8& f1)
 template <int OFF>
 __device__ __forceinline__ bf16x8 lds_read16(unsigned addr) {
   bf16x8 v;
+#ifdef AWT_DIAG_NO_LDSREAD   // timing-only (wrong results): no A fragment reads from LDS (the counted lgkmcnt waits then pass at once)
+  asm volatile("; no ds_read (diag) %0 %1" : "=v"(v) : "v"(addr));
+#else
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+#endif
   return v;
 }
 template <int N> __device__ __forceinline__ void lgkm_wait(bf16x8& f) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(N)); }
@@ -609,6 +613,9 @@ __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, CFG::WM * CFG::WN == 4 ? 2 
   // DMA piece OP (0 .. NDMA - 1) of the K-tile the streams point at
   auto dma = [&](auto op_t, char* stage) {
     constexpr int OP = decltype(op_t)::value;
+#ifdef AWT_DIAG_NO_DMA      // timing-only (wrong results): no activation LDS-DMA after the prologue's
+    if (stage != smem) return;
+#endif
     if constexpr (OP < IT16) {
       const unsigned o = a16o[OP];
       glds16(o != kInvalid ? (const void*)(a16b + o) : (const void*)g.zeros, stage + (OP * NT + wave * 64) * 16);
@@ -624,12 +631,21 @@ __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, CFG::WM * CFG::WN == 4 ? 2 
 
   bf16x8 w16[4][TN];              // fp16 B fragments of the K-tile's four k-steps
   bf16x8 w8[TN][2], wl8[TN][2];   // e4m3 operands (32 bytes = two 16-byte halves)
+#ifdef AWT_DIAG_NO_WLOAD    // timing-only (wrong results): the weight fragments are loaded once, in the prologue
+  bool diag_w_loaded = false;
+#endif
   auto load_w16 = [&](auto ks_t) {
     constexpr int ks = decltype(ks_t)::value;
+#ifdef AWT_DIAG_NO_WLOAD
+    if (diag_w_loaded) return;
+#endif
 #pragma unroll
     for (int j = 0; j < TN; ++j) w16[ks][j] = gload16<ks * 1024>(wl16, w16b[j]);
   };
   auto load_w8 = [&]() {
+#ifdef AWT_DIAG_NO_WLOAD
+    if (diag_w_loaded) return;
+#endif
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       w8[j][0] = gload16<0>(wl32, w8b[j]); w8[j][1] = gload16<16>(wl32, w8b[j]);
@@ -644,6 +660,9 @@ __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, CFG::WM * CFG::WN == 4 ? 2 
   load_w8();
   wait_vm<0>();
   __builtin_amdgcn_s_barrier();
+#ifdef AWT_DIAG_NO_WLOAD
+  diag_w_loaded = true;
+#endif
 
   // A fragment offsets inside a stage: fp16 image row r, chunk (2 ks + half) ^ ((r >> 1) & 7); e4m3 images row r, chunks
   // (2 half + c) ^ ((r >> 2) & 3).  Row tile i adds a multiple of 32 rows, which leaves both swizzle terms unchanged.
