@@ -42,10 +42,7 @@ struct AttnArgs {
 
 __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
 
-__device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
+__device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) { glds16_asm(gsrc, lds_wave_base); }   // common.h: invisible to hipcc's vmcnt bookkeeping
 
 // One K/V tile, global -> LDS.  The source address is a wave-uniform tile base (SGPRs) plus a 32-bit per-lane offset, so the
 // eight DMA instructions share two offset VGPRs instead of eight 64-bit address pairs.

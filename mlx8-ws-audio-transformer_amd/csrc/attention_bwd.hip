@@ -37,10 +37,7 @@ struct BwdArgs {
 };
 
 __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
-__device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
+__device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) { glds16_asm(gsrc, lds_wave_base); }   // common.h: invisible to hipcc's vmcnt bookkeeping
 __device__ __forceinline__ bf16x4 tr_read(const char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)p);
 }

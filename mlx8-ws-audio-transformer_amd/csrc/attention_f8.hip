@@ -44,10 +44,7 @@ __device__ __forceinline__ int swz16(int row) { return (row >> 1) & 7; }        
 __device__ __forceinline__ int swz_k8(int row) { return (row >> 2) & 3; }       // K8 planes: 64-byte rows read by ds_read_b128
 __device__ __forceinline__ int swz_v8(int row) { return ((row >> 3) & 1) << 1; }   // V8 planes: rows k and k + 8 land in different 32-byte halves
 
-__device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
+__device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) { glds16_asm(gsrc, lds_wave_base); }   // common.h: invisible to hipcc's vmcnt bookkeeping
 __device__ __forceinline__ bf16x4 tr_read16(const char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)p);
 }
@@ -323,28 +320,45 @@ __global__ __launch_bounds__(64 * NW, (QT == 1 && NW == 6) ? 3 : 2) void attenti
 // RING3 (the single-product P V form): `stage` is the tile's own slot of a three-deep ring -- K slots [K16 | K8 | Klo8] of 16 KB, V slots
 // [V16] of 8 KB -- instead of a 32 KB stage shared by K and V.
 constexpr int K3_SLOT = PL16 + 2 * PL8, V3_SLOT = PL16, K3_O8 = PL16, K3_OL8 = PL16 + PL8, V3_BASE = 3 * K3_SLOT, RING3_BYTES = 3 * (K3_SLOT + V3_SLOT);
+// Per-lane byte offsets of a wave's LDS-DMA pieces inside a [64 keys x 64 dims] tile (rows past `last` re-read row `last`: the tail tile).
+// Loop-invariant for every tile but the last one of a sequence whose length is not a multiple of 64.
+template <int NW>
+struct KvLaneOff {
+  unsigned o16[8 / NW];      // fp16 planes (K and V share the swizzle)
+  unsigned o8k, o8v;         // e4m3 planes: K (ds_read_b128 swizzle) and V (transposing-read swizzle)
+};
+template <int NW>
+__device__ __forceinline__ KvLaneOff<NW> kv_lane_off(int last, int wave, int lane) {
+  KvLaneOff<NW> o;
+#pragma unroll
+  for (int i = 0; i < 8 / NW; ++i) {
+    const int p = (i * NW + wave) * 64 + lane, row = p >> 3;
+    o.o16[i] = (unsigned)(min(row, last) * 64 + (((p & 7) ^ swz16(row)) << 3)) * 2u;
+  }
+  const int p = (wave & 3) * 64 + lane, row = p >> 2;
+  o.o8k = (unsigned)(min(row, last) * 64 + (((p & 3) ^ swz_k8(row)) << 4));
+  o.o8v = (unsigned)(min(row, last) * 64 + (((p & 3) ^ swz_v8(row)) << 4));
+  return o;
+}
+// K (or V) planes of tile kt -> the LDS slot at byte address `stage` (wave-uniform).  Sources are wave-uniform plane bases (SGPRs) + the lane offsets
+// above, so a copy costs no VALU instruction.
 template <int NW, bool ISK, bool W8 = true, bool RING3 = false>
-__device__ __forceinline__ void stage_kv1(const Attn8Args& a, int64_t head_off, int kt, char* stage, int wave, int lane) {
+__device__ __forceinline__ void stage_kv1(const Attn8Args& a, int64_t head_off, int kt, unsigned stage, int wave, const KvLaneOff<NW>& lo) {
   const int64_t tile_off = head_off + (int64_t)kt * (KB * 64);
-  const int last = a.S - 1 - kt * KB;
   const bf16_t* p16 = (ISK ? a.k16 : a.v16) + tile_off;
   const uint8_t* p8 = (ISK ? a.k8 : a.v8) + tile_off;
   const uint8_t* pl8 = (ISK ? a.kl8 : a.vl8) + tile_off;
   constexpr int O16 = RING3 ? 0 : (ISK ? OFF_K16 : OFF_V16), O8 = RING3 ? K3_O8 : (ISK ? OFF_K8 : OFF_V8), OL8 = RING3 ? K3_OL8 : (ISK ? OFF_KL8 : OFF_VL8);
 #pragma unroll
-  for (int g0 = 0; g0 < 8; g0 += NW) {
-    const int p = (g0 + wave) * 64 + lane, row = p >> 3;
-    glds16(p16 + (unsigned)(min(row, last) * 64 + (((p & 7) ^ swz16(row)) << 3)), stage + O16 + (g0 + wave) * 1024);
-  }
+  for (int i = 0; i < 8 / NW; ++i) glds16_asm_sbase(p16, lo.o16[i], stage + O16 + (i * NW + wave) * 1024);
   if constexpr (!W8) return;          // fp16-only operand (V of the single-product P V): no e4m3 planes to stage
   const int grp = wave & 3;
-  const int p = grp * 64 + lane, row = p >> 2;
-  const unsigned off = (unsigned)(min(row, last) * 64 + (((p & 3) ^ (ISK ? swz_k8(row) : swz_v8(row))) << 4));
+  const unsigned off = ISK ? lo.o8k : lo.o8v;
   if (NW == 4) {
-    glds16(p8 + off, stage + O8 + grp * 1024);
-    glds16(pl8 + off, stage + OL8 + grp * 1024);
+    glds16_asm_sbase(p8, off, stage + O8 + grp * 1024);
+    glds16_asm_sbase(pl8, off, stage + OL8 + grp * 1024);
   } else {
-    glds16((wave < 4 ? p8 : pl8) + off, stage + (wave < 4 ? O8 : OL8) + grp * 1024);
+    glds16_asm_sbase(wave < 4 ? p8 : pl8, off, stage + (wave < 4 ? O8 : OL8) + grp * 1024);
   }
 }
 
@@ -403,50 +417,79 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f16f8_pipe_kernel(Attn8A
   //   slots 20..23  O^T += V8^T Pl8^T + Vl8^T P8^T  (et x 2)
   //                 (PV8 only; without it P V is the single fp16 product: P in [0, 1] rounds to 11 significant bits and the
   //                  normaliser is the sum of the unrounded P -- DESIGN.md "Numerics" for what that costs)
-  constexpr int NSLOT = PV8 ? 24 : 20, DEPTH = 2;
+#ifndef AWT_ATTN_DEPTH
+#define AWT_ATTN_DEPTH 2
+#endif
+  constexpr int NSLOT = PV8 ? 24 : 20, DEPTH = AWT_ATTN_DEPTH, RING = DEPTH + 1;   // fragments are read DEPTH slots ahead of their MFMA
   // LDS: PV8 -- two 32 KB stages shared by K and V (K staged two tiles ahead, V one).  !PV8 -- three-deep rings (K three tiles ahead,
   // V two): a tile's LDS-DMA then has two iterations (~4 us) to land instead of one, and the wait at the end of an iteration only covers
   // the loads of the iteration before (counted vmcnt).  With one iteration of slack the timing-only build without the wait ran 18 % faster.
   constexpr bool RING3 = !PV8;
   constexpr int KO8 = RING3 ? K3_O8 : OFF_K8, KOL8 = RING3 ? K3_OL8 : OFF_KL8, VO16 = RING3 ? 0 : OFF_V16;
-  auto kslot = [&](int t) -> char* { return RING3 ? smem + (t % 3) * K3_SLOT : smem + (t & 1) * STAGE; };
-  auto vslot = [&](int t) -> char* { return RING3 ? smem + V3_BASE + (t % 3) * V3_SLOT : smem + (t & 1) * STAGE; };
-  auto read_slot = [&](auto slot_t, const char* kst, const char* vst, i32x8& f) {
+  // LDS byte addresses (not pointers: the per-lane read addresses below are plain 32-bit integers the compiler cannot re-derive per read)
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)(smem);
+  auto kslot = [&](int t) -> unsigned { return RING3 ? lds0 + (t % 3) * K3_SLOT : lds0 + (t & 1) * STAGE; };
+  auto vslot = [&](int t) -> unsigned { return RING3 ? lds0 + V3_BASE + (t % 3) * V3_SLOT : lds0 + (t & 1) * STAGE; };
+  // Per-lane read addresses of the K slot / V slot an iteration works on: slot base + the loop-invariant lane offsets, formed ONCE per iteration
+  // (eight to ten adds) and pinned in registers; every read then uses one of them plus an immediate offset.  Left to itself the compiler rebuilt
+  // slot base + lane offset + constant per read: ~35 VALU instructions per iteration in a kernel that is bound by vector-instruction issue.
+  struct RdAddr { unsigned k16[4], k8[2], v0, v1, v8[2]; };
+  auto rd_addr = [&](unsigned kb, unsigned vb) {
+    RdAddr r;
+    constexpr bool PIN = !PV8;      // the every-cross-term form has no registers to spare for pinned addresses (it spilled): the compiler keeps its own way there
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) { r.k16[ks] = kb + koff[ks]; if constexpr (PIN) asm volatile("" : "+v"(r.k16[ks])); }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) { r.k8[c] = kb + k8off[c]; if constexpr (PIN) asm volatile("" : "+v"(r.k8[c])); }
+    r.v0 = vb + VO16 + voff; r.v1 = vb + VO16 + voffx;
+    if constexpr (PIN) asm volatile("" : "+v"(r.v0), "+v"(r.v1));
+    if constexpr (PV8) { r.v8[0] = vb + v8off; r.v8[1] = vb + (v8off ^ 32); }
+    else r.v8[0] = r.v8[1] = 0;
+    return r;
+  };
+  auto lds128 = [](unsigned addr) { return *(const __attribute__((address_space(3))) i32x4_t*)(uintptr_t)addr; };
+  auto read_slot = [&](auto slot_t, const RdAddr& ra, i32x8& f) {
     constexpr int SLOT = decltype(slot_t)::value;
     if constexpr (SLOT < 12) {
       constexpr int kt2 = SLOT / 6, w = SLOT % 6;
       if constexpr (w < 2) {
-        const char* pl = kst + (w == 0 ? KO8 : KOL8) + kt2 * 2048;
-        const uint4 x0 = *reinterpret_cast<const uint4*>(pl + k8off[0]), x1 = *reinterpret_cast<const uint4*>(pl + k8off[1]);
-        f = (i32x8){(int)x0.x, (int)x0.y, (int)x0.z, (int)x0.w, (int)x1.x, (int)x1.y, (int)x1.z, (int)x1.w};
+        constexpr int pl = (w == 0 ? KO8 : KOL8) + kt2 * 2048;
+        const i32x4_t x0 = lds128(ra.k8[0] + pl), x1 = lds128(ra.k8[1] + pl);
+        f = (i32x8){x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
       } else {
-        const uint4 x0 = *reinterpret_cast<const uint4*>(kst + koff[w - 2] + kt2 * 4096);
-        f[0] = (int)x0.x; f[1] = (int)x0.y; f[2] = (int)x0.z; f[3] = (int)x0.w;
+        const i32x4_t x0 = lds128(ra.k16[w - 2] + kt2 * 4096);
+        f[0] = x0[0]; f[1] = x0[1]; f[2] = x0[2]; f[3] = x0[3];
       }
     } else if constexpr (SLOT < 20) {
       constexpr int I = SLOT - 12, kt2 = I >> 2, s2 = (I >> 1) & 1, et = I & 1;
       constexpr int cst = kt2 * 4096 + s2 * 2048;
-      const int off0 = (et == 0 ? voff : voffx) + cst;
-      const int off1 = (et == 0 ? voffx : voff) + cst + 1024;
-      const i32x2 va = __builtin_bit_cast(i32x2, tr_read16(vst + VO16 + off0)), vb = __builtin_bit_cast(i32x2, tr_read16(vst + VO16 + off1));
-      f[0] = va[0]; f[1] = va[1]; f[2] = vb[0]; f[3] = vb[1];
+      const unsigned a0 = (et == 0 ? ra.v0 : ra.v1) + cst, a1 = (et == 0 ? ra.v1 : ra.v0) + cst + 1024;
+      const i32x2 va = __builtin_bit_cast(i32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(uintptr_t)a0));
+      const i32x2 vb2 = __builtin_bit_cast(i32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(uintptr_t)a1));
+      f[0] = va[0]; f[1] = va[1]; f[2] = vb2[0]; f[3] = vb2[1];
     } else {
       constexpr int I = SLOT - 20, et = I >> 1, lo = I & 1;
 #pragma unroll
       for (int n = 0; n < 4; ++n) {
-        const i32x2 x = tr_read8(vst + (lo ? OFF_VL8 : OFF_V8) + ((v8off ^ (et << 5)) + n * 1024));
+        const i32x2 x = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) i32x2*)(uintptr_t)(ra.v8[et] + (lo ? OFF_VL8 : OFF_V8) + n * 1024));
         f[2 * n] = x[0]; f[2 * n + 1] = x[1];
       }
     }
   };
+  // LDS-DMA lane offsets: loop-invariant except for the tail tile of a sequence that is not a multiple of 64 keys (rows past its end re-read its last row)
+  const KvLaneOff<NW> lo_full = kv_lane_off<NW>(KB - 1, wave, lane);
+  auto lane_off = [&](int t) -> KvLaneOff<NW> {
+    if ((a.S % KB) != 0 && t == ntiles - 1) return kv_lane_off<NW>(a.S - 1 - t * KB, wave, lane);
+    return lo_full;
+  };
 
   // prologue: K(0), V(0) -> stage 0, K(1) -> stage 1; S(0)
-  stage_kv1<NW, true, true, RING3>(a, head_off, 0, kslot(0), wave, lane);
-  stage_kv1<NW, false, PV8, RING3>(a, head_off, 0, vslot(0), wave, lane);
-  if (ntiles > 1) stage_kv1<NW, true, true, RING3>(a, head_off, 1, kslot(1), wave, lane);
+  stage_kv1<NW, true, true, RING3>(a, head_off, 0, kslot(0), wave, lane_off(0));
+  stage_kv1<NW, false, PV8, RING3>(a, head_off, 0, vslot(0), wave, lane_off(0));
+  if (ntiles > 1) stage_kv1<NW, true, true, RING3>(a, head_off, 1, kslot(1), wave, lane_off(1));
   if constexpr (RING3) {
-    if (ntiles > 1) stage_kv1<NW, false, PV8, RING3>(a, head_off, 1, vslot(1), wave, lane);
-    if (ntiles > 2) stage_kv1<NW, true, true, RING3>(a, head_off, 2, kslot(2), wave, lane);
+    if (ntiles > 1) stage_kv1<NW, false, PV8, RING3>(a, head_off, 1, vslot(1), wave, lane_off(1));
+    if (ntiles > 2) stage_kv1<NW, true, true, RING3>(a, head_off, 2, kslot(2), wave, lane_off(2));
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -461,13 +504,13 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f16f8_pipe_kernel(Attn8A
     }
   };
   {
-    i32x8 ring[3];
-    read_slot(std::integral_constant<int, 0>{}, kslot(0), vslot(0), ring[0]);
-    read_slot(std::integral_constant<int, 1>{}, kslot(0), vslot(0), ring[1]);
+    i32x8 ring[RING];
+    const RdAddr ra0 = rd_addr(kslot(0), vslot(0));
+    [&]<int... P>(std::integer_sequence<int, P...>) { (read_slot(std::integral_constant<int, P>{}, ra0, ring[P]), ...); }(std::make_integer_sequence<int, DEPTH>{});
     [&]<int... I>(std::integer_sequence<int, I...>) {
       ([&] {
-        if constexpr (I + DEPTH < 12) read_slot(std::integral_constant<int, I + DEPTH>{}, kslot(0), vslot(0), ring[(I + DEPTH) % 3]);
-        qk_mma(std::integral_constant<int, I>{}, ring[I % 3], sa);
+        if constexpr (I + DEPTH < 12) read_slot(std::integral_constant<int, I + DEPTH>{}, ra0, ring[(I + DEPTH) % RING]);
+        qk_mma(std::integral_constant<int, I>{}, ring[I % RING], sa);
       }(), ...);
     }(std::make_integer_sequence<int, 12>{});
   }
@@ -480,16 +523,15 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f16f8_pipe_kernel(Attn8A
   auto iter = [&](auto last_t, auto tail_t, int kt, f32x16 (&sc)[2], f32x16 (&sn)[2]) {
     constexpr bool LAST = decltype(last_t)::value, TAIL = decltype(tail_t)::value;
     constexpr int FIRST = LAST ? 12 : 0;                  // the last tile has no next scores to compute
-    const char* cur = vslot(kt);                          // V(kt)
-    const char* oth = kslot(kt + 1);                      // K(kt + 1)
+    const RdAddr ra = rd_addr(kslot(kt + 1), vslot(kt));   // K(kt + 1) for the next scores, V(kt) for this tile's output
 #ifndef AWT_DIAG8_NO_STAGE   // AWT_DIAG8_*: timing-only builds (tools/build_attn8_variants.sh), wrong results, never shipped
     if constexpr (!LAST) {
       if constexpr (RING3) {                              // K(kt + 3) takes K(kt)'s slot, V(kt + 2) takes V(kt - 1)'s
-        if (kt + 3 < ntiles) stage_kv1<NW, true, true, true>(a, head_off, kt + 3, kslot(kt), wave, lane);
-        if (kt + 2 < ntiles) stage_kv1<NW, false, false, true>(a, head_off, kt + 2, vslot(kt + 2), wave, lane);
+        if (kt + 3 < ntiles) stage_kv1<NW, true, true, true>(a, head_off, kt + 3, kslot(kt), wave, lane_off(kt + 3));
+        if (kt + 2 < ntiles) stage_kv1<NW, false, false, true>(a, head_off, kt + 2, vslot(kt + 2), wave, lane_off(kt + 2));
       } else {                                            // K(kt + 2) takes K(kt)'s half of the stage, V(kt + 1) V(kt - 1)'s
-        if (kt + 2 < ntiles) stage_kv1<NW, true>(a, head_off, kt + 2, kslot(kt), wave, lane);
-        stage_kv1<NW, false, PV8>(a, head_off, kt + 1, vslot(kt + 1), wave, lane);
+        if (kt + 2 < ntiles) stage_kv1<NW, true>(a, head_off, kt + 2, kslot(kt), wave, lane_off(kt + 2));
+        stage_kv1<NW, false, PV8>(a, head_off, kt + 1, vslot(kt + 1), wave, lane_off(kt + 1));
       }
     }
 #endif
@@ -560,19 +602,18 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f16f8_pipe_kernel(Attn8A
         else oacc[et] = mfma32_f8<e8m0(-kF8KV - kF8Lo), e8m0(-kF8P)>(f, p8, oacc[et]);
       }
     };
-    i32x8 ring[3];
-    read_slot(std::integral_constant<int, FIRST>{}, oth, cur, ring[FIRST % 3]);
-    read_slot(std::integral_constant<int, FIRST + 1>{}, oth, cur, ring[(FIRST + 1) % 3]);
+    i32x8 ring[RING];
+    [&]<int... P>(std::integer_sequence<int, P...>) { (read_slot(std::integral_constant<int, FIRST + P>{}, ra, ring[(FIRST + P) % RING]), ...); }(std::make_integer_sequence<int, DEPTH>{});
     if constexpr (LAST) {   // no S^T MFMAs to hide the softmax behind
       [&]<int... C>(std::integer_sequence<int, C...>) { (valu_chunk(std::integral_constant<int, C>{}), ...); }(std::make_integer_sequence<int, 12>{});
     }
     [&]<int... J>(std::integer_sequence<int, J...>) {
       ([&] {
         constexpr int I = FIRST + J;
-        if constexpr (I + DEPTH < NSLOT) read_slot(std::integral_constant<int, I + DEPTH>{}, oth, cur, ring[(I + DEPTH) % 3]);
+        if constexpr (I + DEPTH < NSLOT) read_slot(std::integral_constant<int, I + DEPTH>{}, ra, ring[(I + DEPTH) % RING]);
         if constexpr (!LAST || I >= 12) valu_chunk(std::integral_constant<int, I>{});
         __builtin_amdgcn_sched_barrier(0);
-        mma(std::integral_constant<int, I>{}, ring[I % 3]);
+        mma(std::integral_constant<int, I>{}, ring[I % RING]);
         __builtin_amdgcn_sched_barrier(0);
       }(), ...);
     }(std::make_integer_sequence<int, NSLOT - FIRST>{});

@@ -146,6 +146,30 @@ __device__ __forceinline__ void f16f8x4(const float (&v)[4], uint2& h16, unsigne
   lo8 = fp8x4<S + kF8Lo>(l[0], l[1], l[2], l[3]);
 }
 
+// 16-byte LDS-DMA (global -> LDS without a register stage; the LDS destination is the wave-uniform base + lane * 16) that hipcc does NOT see.
+// With the builtin (__builtin_amdgcn_global_load_lds) the compiler knows an LDS write is in flight on the vector-memory counter and, unable to
+// prove that a later ordinary LDS read does not alias it, puts `s_waitcnt vmcnt(0)` in front of the first ds_read that follows: in the attention
+// kernels that was the first fragment read of the iteration, i.e. every iteration waited for the K / V tiles it had JUST requested for two
+// iterations later, and the multi-stage rings bought nothing (disassembly, round 3; cdna_hip_programming.md section 5 "Three .s-level traps" (b)).
+// As inline asm the copy is invisible to that bookkeeping; every kernel that uses it waits with its own counted `s_waitcnt vmcnt(N)` in front of
+// the barrier that publishes the tile (vmcnt retires in issue order).  M0 (the destination base) is compiler-reserved: saved and restored here.
+__device__ __forceinline__ void glds16_asm(const void* gsrc, char* lds_wave_base) {
+  const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds_wave_base);
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
+
+// The same with the source as a wave-uniform base (SGPR pair) plus a 32-bit per-lane byte offset and the destination as an LDS byte address:
+// a loop whose lane offsets are invariant spends no VALU instruction on the copy's addresses (the 64-bit per-lane pointer of the form above
+// costs a v_lshl_add_u64 or two per copy).
+__device__ __forceinline__ void glds16_asm_sbase(const void* sbase, unsigned lane_byte_off, unsigned lds_wave_addr) {
+  const unsigned dst = __builtin_amdgcn_readfirstlane(lds_wave_addr);
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(lane_byte_off), "s"(sbase), "s"(dst) : "memory");
+}
+
 // erf to 1.5e-7 absolute (Abramowitz & Stegun 7.1.26: five-term polynomial in 1 / (1 + p |x|) times exp(-x^2)) in ~12
 // instructions; libm's erff costs ~3x that, and the MLP GEMM epilogue evaluates 295 M of them per layer at B = 64.
 __device__ __forceinline__ float erf_fast(float x) {

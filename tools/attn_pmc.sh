@@ -16,7 +16,8 @@ _lib.tuning_set("attn_shape", shape)
 for _ in range(6): ops.attention(q, k, v, prec)
 torch.cuda.synchronize()
 PY
-for cfg in "bf16x3 0" "f16f8 1" "f16f8 2" "f16f8 3"; do
+IFS=";" read -ra CFGS <<< "${AWT_PMC_CFGS:-bf16x3 0;f16f8 1;f16f8 2;f16f8 3}"
+for cfg in "${CFGS[@]}"; do
   set -- $cfg
   for pass in A B; do
     if [ $pass = A ]; then ctr="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"
