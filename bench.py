@@ -376,6 +376,10 @@ def finetune_main(a):
                            a.lora_r, "torch" if a.torch_decoder else "HIP"),
                        "clips_per_gpu_per_step": B, "global_batch": B * world, "precision": a.precision, "label_tokens": 12, "decoder_dtype": a.decoder_dtype,
                        "backward_precision": a.backward_precision or a.precision,
+                       "decoder_cross_attention": ("torch" if a.torch_decoder else
+                                                   "absorbed (q_h W_k,h against the encoder states, batched GEMMs; native_decoder._AbsorbedCross)"
+                                                   if getattr(model.decoder, "absorbed_cross", lambda *_: False)(12, cfg.max_source_positions)
+                                                   else "projected keys / values (cross_kv)"),
                        "weights": "seed-0 random init, arbitrary fp32 values (SURVEY.md 8(d) C3); adapters A ~ N(0, 1/d), B = 0",
                        "adapter_grad_elems": tr.bucket.numel, "gradient_exchange": tr.exchange,
                        "parallelism": "dp%d, one in-place mean all-reduce of %.2f MB per step" % (world, tr.bucket.numel * 4 / 1e6)},

@@ -247,6 +247,28 @@ int awt_linear_forward(awt_ctx* c, const awt_weight* w, const float* x, const fl
 /* dx [M, K] = dy [M, Np] W                                             (frozen weight: no weight gradient) */
 int awt_linear_backward_input(awt_ctx* c, const awt_weight* w, const float* dy, float* dx, int M, void* workspace, size_t ws_bytes,
                               void* stream);
+/* Batched products C_z [M, N] = A_z [M, K] B_z [N, K]^T (+ resid_z, may alias C_z), z < batch, split-bf16 operands on the MFMA GEMM, one launch.
+ * The operators of the decoder's cross-attention in its ABSORBED form (HF:modeling_whisper.py:284-356 with `key_value_states`, re-associated:
+ * q_h K_h^T = (q_h W_k,h) enc^T and P_h V_h = (P_h enc) W_v,h^T + b_v, so that with L ~ 12 label rows per clip the key / value projections
+ * of the B x 1500 encoder rows are never computed; csrc/bmm.hip).  B_z is written once by awt_bmm_pack into the GEMM's weight layout (zero-padded
+ * to N % 128 == 0, K % 64 == 0) and reused by every product against it; A_z, resid_z and C_z are row-major fp32 with pitches lda / ldo and strides
+ * stride_a / stride_o between matrices (elements; strided views inside larger matrices are fine).  N, ldo, stride_o: multiples of 4. */
+size_t awt_bmm_packed_bytes(int batch, int N, int K);
+int awt_bmm_pack(awt_ctx* c, const float* b, int64_t ldb, int64_t stride_b, int batch, int N, int K, void* packed, size_t packed_bytes, void* stream);
+size_t awt_bmm_workspace_bytes(int batch, int M, int K);
+int awt_bmm(awt_ctx* c, const float* a, int64_t lda, int64_t stride_a, const void* packed_b, const float* resid, float* out, int64_t ldo,
+            int64_t stride_o, int batch, int M, int N, int K, void* workspace, size_t ws_bytes, void* stream);
+/* The same with an operand given K-MAJOR (i.e. transposed in memory), optionally as two matrices stacked along K:
+ * X[n, k] = (k < K1 ? x1 : x2)[z * stride + (k < K1 ? k : k - K1) * ld + n]; x2 may be NULL when K1 == K.  The backward's
+ * d(enc)_b = [P_b^T | dS_b^T] [d(context)_b ; q~_b] reads all four matrices where they lie. */
+int awt_bmm_pack_kmajor(awt_ctx* c, const float* b1, const float* b2, int K1, int64_t ldb, int64_t stride_b, int batch, int N, int K, void* packed,
+                        size_t packed_bytes, void* stream);
+int awt_bmm_kmajor(awt_ctx* c, const float* a1, const float* a2, int K1, int64_t lda, int64_t stride_a, const void* packed_b, const float* resid, float* out,
+                   int64_t ldo, int64_t stride_o, int batch, int M, int N, int K, void* workspace, size_t ws_bytes, void* stream);
+/* p[r, :] = softmax(scale * s[r, :]) over cols <= 4096 columns (pitch ld; p may alias s), and its backward
+ * ds[r, :] = scale * p[r, :] * (dp[r, :] - sum_c p[r, c] dp[r, c]) (ds may alias dp)                      HF:modeling_whisper.py:226-231 */
+int awt_op_softmax_rows(awt_ctx* c, const float* s, float* p, int rows, int cols, int64_t ld, float scale, void* stream);
+int awt_op_softmax_rows_backward(awt_ctx* c, const float* p, const float* dp, float* ds, int rows, int cols, int64_t ld, float scale, void* stream);
 /* x[m, :] = embed_tokens[ids[m], :] + embed_positions[pos0 + m % L, :]     HF:modeling_whisper.py:756-770 */
 int awt_op_embed(awt_ctx* c, const int64_t* ids, const float* tok, const float* pos, float* x, int M, int L, int d, int pos0, int vocab,
                  void* stream);

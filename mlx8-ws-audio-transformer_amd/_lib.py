@@ -82,6 +82,14 @@ _SIGNATURES = {
     "awt_linear_workspace_bytes": (_sz, [_vp, _i, _i]),
     "awt_linear_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "awt_linear_backward_input": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
+    "awt_bmm_packed_bytes": (_sz, [_i, _i, _i]),
+    "awt_bmm_pack": (_i, [_vp, _vp, _i64, _i64, _i, _i, _i, _vp, _sz, _vp]),
+    "awt_bmm_workspace_bytes": (_sz, [_i, _i, _i]),
+    "awt_bmm": (_i, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "awt_bmm_pack_kmajor": (_i, [_vp, _vp, _vp, _i, _i64, _i64, _i, _i, _i, _vp, _sz, _vp]),
+    "awt_bmm_kmajor": (_i, [_vp, _vp, _vp, _i, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "awt_op_softmax_rows": (_i, [_vp, _vp, _vp, _i, _i, _i64, _f, _vp]),
+    "awt_op_softmax_rows_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i64, _f, _vp]),
     "awt_op_embed": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "awt_op_gelu": (_i, [_vp, _vp, _vp, _i64, _vp]),
     "awt_op_gelu_backward": (_i, [_vp, _vp, _vp, _vp, _i64, _vp]),

@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libawt.so")
-SOURCES = ["awt_api.hip", "logmel.hip", "gemm.hip", "attention.hip", "attention_f8.hip", "attention_bwd.hip", "elementwise.hip", "comm.hip", "decoder_ops.hip"]
+SOURCES = ["awt_api.hip", "logmel.hip", "gemm.hip", "attention.hip", "attention_f8.hip", "attention_bwd.hip", "elementwise.hip", "comm.hip", "decoder_ops.hip", "bmm.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 

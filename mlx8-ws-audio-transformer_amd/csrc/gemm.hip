@@ -47,6 +47,9 @@ struct GemmArgs {
   GemmSeg seg[kMaxSeg];
   GemmOut out;
   const bf16_t* zeros;   // >= 128 zero bytes (padding rows of the conv stem)
+  // batched launch (gemm_kernel<..., BATCH = true>, blockIdx.y = matrix index): element strides of segment 0's activation planes,
+  // of its fragment-major weight planes and of the fp32 output / residual between consecutive matrices
+  int64_t bs_a, bs_w, bs_o;
 };
 
 // block-tile configurations: WM x WN waves, each wave TM x TN tiles of 16 x 16
@@ -91,6 +94,7 @@ struct Stager {
   const bf16_t* a_hi[T::ITERS_A]; const bf16_t* a_lo[T::ITERS_A];
   const bf16_t* w_hi; const bf16_t* w_lo;     // lane's 16 bytes of fragment block (n-tile of the wave's first column tile, k-step w_k0)
   int64_t w_tile_stride;                       // elements between consecutive n-tiles = ksteps * 512
+  int64_t za = 0, zw = 0;                      // batched launch: this matrix' offset into the activation / weight planes (0 otherwise: folded away)
   int si, kk, nk;
 
   __device__ __forceinline__ void open_segment(const GemmArgs& g, int seg, int m0, int n0, int wc, int wave, int lane) {
@@ -109,13 +113,13 @@ struct Stager {
       const int grp = m / sg.rows_out, r = m - grp * sg.rows_out;
       const int sr = r * sg.row_mul + sg.row_add;               // conv stem: 2 s + tap - 1
       const bool ok = (sr >= 0) && (sr < sg.rows_in);
-      const int64_t aoff = ((int64_t)grp * sg.rows_in + sr) * sg.lda + c * 8;
+      const int64_t aoff = ((int64_t)grp * sg.rows_in + sr) * sg.lda + c * 8 + za;
       a_hi[it] = ok ? sg.a_hi + aoff : nullptr;
       a_lo[it] = (ok && TERMS == 3) ? sg.a_lo + aoff : nullptr;
     }
     w_tile_stride = (int64_t)sg.w_ksteps * 512;
     const int nt0 = (n0 >> 4) + wc * CFG::TN;                   // the wave's first 16-column tile
-    const int64_t woff = ((int64_t)nt0 * sg.w_ksteps + sg.w_k0) * 512 + lane * 8;
+    const int64_t woff = ((int64_t)nt0 * sg.w_ksteps + sg.w_k0) * 512 + lane * 8 + zw;
     w_hi = sg.w_hi + woff;
     w_lo = (TERMS == 3) ? sg.w_lo + woff : nullptr;
   }
@@ -295,8 +299,9 @@ __device__ __forceinline__ void store_out8_f8(const GemmOut& o, int m, int n, fl
   *reinterpret_cast<uint2*>(o.lo8 + off) = make_uint2(fp8x4_rt(l[0], l[1], l[2], l[3], liml8, invl8), fp8x4_rt(l[4], l[5], l[6], l[7], liml8, invl8));
 }
 
-template <int TERMS, int BK, int EPI, class CFG, bool F16, bool WX = false>
+template <int TERMS, int BK, int EPI, class CFG, bool F16, bool WX = false, bool BATCH = false>
 __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, 2) void gemm_kernel(GemmArgs g) {
+  static_assert(!BATCH || EPI == EPI_F32 || EPI == EPI_F32_RESID, "batched launches write fp32 matrices");
   static_assert(!WX || TERMS == 3, "the exact-weight form belongs to the split product");
   using T = Tile<TERMS, BK, CFG, WX>;
   using ST = Stager<TERMS, BK, CFG, WX>;
@@ -345,6 +350,7 @@ __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, 2) void gemm_kernel(GemmArg
 
   bf16x8 bh[KS][TN], bl[KS][TN], nbh[KS][TN], nbl[KS][TN], ah[2], al[2];
   ST st;
+  if constexpr (BATCH) { st.za = (int64_t)blockIdx.y * g.bs_a; st.zw = (int64_t)blockIdx.y * g.bs_w; }
   st.open_segment(g, 0, m0, n0, wc, wave, lane);
   // prologue: K-tile 0 -- A into LDS stage 0 (burst), W fragments into the "next" registers
   auto issue_all = [&](char* stage) {
@@ -418,11 +424,14 @@ __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, 2) void gemm_kernel(GemmArg
   const int em0 = m0 + wr * TM * 16, en = n0 + wc * 64 + frow * 4;
   float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (g.out.bias && en < g.out.n_valid) bias4 = *reinterpret_cast<const float4*>(g.out.bias + en);
+  GemmOut out_z;                               // batched launch: the output / residual of this matrix
+  if constexpr (BATCH) { out_z = g.out; out_z.f32 += (int64_t)blockIdx.y * g.bs_o; if (out_z.resid) out_z.resid += (int64_t)blockIdx.y * g.bs_o; }
+  const GemmOut& gout = BATCH ? out_z : g.out;
   auto strips = [&](auto full_t) {
     constexpr bool FULL = decltype(full_t)::value;
     float4 side[4], side_next[4];
 #pragma unroll
-    for (int it = 0; it < 4; ++it) side[it] = load_side4<EPI, FULL>(g.out, em0 + fq + 4 * it, en, g.M);
+    for (int it = 0; it < 4; ++it) side[it] = load_side4<EPI, FULL>(gout, em0 + fq + 4 * it, en, g.M);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -431,7 +440,7 @@ __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, 2) void gemm_kernel(GemmArg
         for (int rr = 0; rr < 4; ++rr) patch[(fq * 4 + rr) * PITCH + j * 16 + frow] = acc[i][j][rr];
       if (i + 1 < TM) {
 #pragma unroll
-        for (int it = 0; it < 4; ++it) side_next[it] = load_side4<EPI, FULL>(g.out, em0 + (i + 1) * 16 + fq + 4 * it, en, g.M);
+        for (int it = 0; it < 4; ++it) side_next[it] = load_side4<EPI, FULL>(gout, em0 + (i + 1) * 16 + fq + 4 * it, en, g.M);
       }
       __builtin_amdgcn_wave_barrier();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -439,7 +448,7 @@ __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, 2) void gemm_kernel(GemmArg
       for (int it = 0; it < 4; ++it) {
         const int rl = fq + 4 * it;
         const float4 v = *reinterpret_cast<const float4*>(patch + rl * PITCH + frow * 4);
-        store_out4<EPI, F16 ? PREC_F16X3 : PREC_BF16X3, FULL>(g.out, em0 + i * 16 + rl, en, v, side[it], bias4, g.M);
+        store_out4<EPI, F16 ? PREC_F16X3 : PREC_BF16X3, FULL>(gout, em0 + i * 16 + rl, en, v, side[it], bias4, g.M);
       }
 #pragma unroll
       for (int it = 0; it < 4; ++it) side[it] = side_next[it];
@@ -1129,6 +1138,19 @@ int g_force_tile = 0;  // 0 = auto, 64 / 128 / 256 = forced (tuning and tests)
 // panels, so row-panel groups are the default; AWT_GEMM_GROUP_N=n selects column groups for experiments.
 int g_group_n = 0;
 
+// batched launch (launch_gemm_batched): `batch` independent matrices of one shape, blockIdx.y = matrix
+template <int TERMS, int BK, int EPI, class CFG>
+int launch_batched_one(GemmArgs a, int batch, hipStream_t s) {
+  using T = Tile<TERMS, BK, CFG, false>;
+  AWT_ONCE_PER_DEVICE(AWT_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_kernel<TERMS, BK, EPI, CFG, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES)));
+  a.tiles_m = (a.M + T::BM - 1) / T::BM;
+  a.tiles_n = (a.N + T::BN - 1) / T::BN;
+  a.group_n = 0; a.gm = g_gm;
+  hipLaunchKernelGGL((gemm_kernel<TERMS, BK, EPI, CFG, false, false, true>), dim3(a.tiles_m * a.tiles_n, batch), dim3(T::THREADS), T::LDS_BYTES, s, a);
+  AWT_HIP_CHECK(hipGetLastError());
+  return AWT_OK;
+}
+
 template <int TERMS, int BK, int EPI, class CFG, bool F16 = false, bool WX = false>
 int launch_one(GemmArgs a, hipStream_t s) {
   using T = Tile<TERMS, BK, CFG, WX>;
@@ -1200,7 +1222,40 @@ int launch_epi(GemmArgs a, int prec, hipStream_t s) {
 }
 
 
+template <int EPI>
+int launch_batched_epi(GemmArgs a, int batch, hipStream_t s) {
+  // tile by the rows a matrix wastes: 64-row tiles when the last 128-row tile would be at most half full or the launch is small
+  const int64_t t256 = (int64_t)((a.M + 127) / 128) * (a.N / 256) * batch, t128 = (int64_t)((a.M + 127) / 128) * (a.N / 128) * batch;
+  const int tail = a.M % 128;
+  int tile = g_force_tile;
+  if (!tile) tile = (tail > 0 && tail <= 64 && a.M < 1024) ? 64 : (a.N % 256 == 0 && t256 >= kSlots) ? 256 : (t128 >= kSlots ? 128 : 64);
+  if (tile == 256 && a.N % 256 != 0) tile = 128;
+  if (tile == 256) return launch_batched_one<3, 32, EPI, CfgW4>(a, batch, s);
+  if (tile == 128) return launch_batched_one<3, 32, EPI, Cfg128>(a, batch, s);
+  return launch_batched_one<3, 64, EPI, Cfg64>(a, batch, s);
+}
+
 }  // namespace
+
+// C_z [M, N] = A_z [M, K] . W_z [N, K]^T (+ resid_z) for z < batch: split-bf16 operands, fp32 output.  A: row-major hi / lo planes, matrix z at
+// element offset z * bs_a; W: fragment-major hi / lo planes of [N, K] (w_frag_index), matrix z at z * bs_w; out / resid: z * bs_o.
+int launch_gemm_batched(awt_ctx* c, int batch, int M, int N, int K, const bf16_t* a_hi, const bf16_t* a_lo, int64_t lda, int64_t bs_a, const bf16_t* w_hi,
+                        const bf16_t* w_lo, int64_t bs_w, float* out, const float* resid, int64_t ldo, int64_t bs_o, int n_valid, hipStream_t s) {
+  AWT_REQUIRE(c && c->zeros && batch > 0 && batch <= 65535 && M > 0 && N > 0 && N % 128 == 0 && K > 0 && K % 64 == 0, AWT_ERR_INVALID,
+              "gemm (batched): 1..65535 matrices, N % 128 == 0 and K % 64 == 0 required");
+  AWT_REQUIRE(a_hi && a_lo && w_hi && w_lo && out && lda % 8 == 0 && lda >= K && ldo % 4 == 0 && n_valid > 0 && n_valid <= N && n_valid % 4 == 0 && ldo >= n_valid, AWT_ERR_INVALID,
+              "gemm (batched): null plane, lda not a multiple of 8, or output columns / pitch not a multiple of 4");
+  AWT_REQUIRE(bs_a % 8 == 0 && bs_w % 8 == 0 && bs_o % 4 == 0, AWT_ERR_INVALID, "gemm (batched): matrix strides must keep 16-byte alignment");
+  GemmArgs a{};
+  a.M = M; a.N = N; a.nseg = 1; a.zeros = (const bf16_t*)c->zeros;
+  GemmSeg& sg = a.seg[0];
+  sg.a_hi = a_hi; sg.a_lo = a_lo; sg.lda = lda; sg.w_hi = w_hi; sg.w_lo = w_lo; sg.w_ksteps = K / 32; sg.w_k0 = 0; sg.K = K;
+  sg.rows_out = sg.rows_in = M; sg.row_mul = 1; sg.row_add = 0;
+  a.out.f32 = out; a.out.resid = resid; a.out.ldo = ldo; a.out.n_valid = n_valid;
+  a.bs_a = bs_a; a.bs_w = bs_w; a.bs_o = bs_o;
+  ProfScope prof(c, AWT_PROF_GEMM, s, 2.0 * (double)batch * (double)M * (double)n_valid * (double)K);
+  return resid ? launch_batched_epi<EPI_F32_RESID>(a, batch, s) : launch_batched_epi<EPI_F32>(a, batch, s);
+}
 
 void awt_gemm_force_tile(int t) { g_force_tile = t; }
 void awt_gemm_set_gm(int v) { g_gm = v > 0 ? v : AWT_GEMM_GM; }

@@ -12,6 +12,13 @@ d(encoder hidden states), and the whole decoder + loss is a single autograd node
 tensors beyond the activations the native backward needs, and the twelve layers' cross-attention key / value gradients are written
 side by side into one buffer that a single GEMM turns into d(encoder hidden states).
 
+Cross-attention in the training step runs in its ABSORBED form (`_AbsorbedCross`, csrc/bmm.hip): with L ~ 12 label rows per clip the key /
+value projections of the B x 1500 encoder rows (2 x 768 x 768 MACs per row and decoder layer, forward and backward, plus a 7 GB key / value
+tensor and its gradient at B = 64) are re-associated onto the query side -- scores = (q_h W_k,h) enc^T, context = (P_h enc) W_v,h^T + b_v --
+so that each layer costs two [H L, d] x [d, S] products per clip against the encoder states themselves (packed once per step as the GEMM's B
+operand and shared by all layers, forward and backward).  Exact re-association: results differ from the key / value form by rounding only.
+`generate` / `forward` (many decoding steps against the same clip) keep the projected keys / values (`cross_kv`).
+
 Parameter names are HF's (`WhisperDecoder.state_dict()` loads unchanged); `forward` has `finetune.WhisperDecoder`'s signature, so
 `greedy_decode` / `generate` run on it as well (incremental decoding with a self-attention cache).
 
@@ -150,6 +157,153 @@ def gemm(x: torch.Tensor, w: torch.Tensor, precision: str = "bf16x3") -> torch.T
     return ops.linear(x.contiguous(), w.contiguous(), None, precision)[:, :N]
 
 
+class PackedBatch:
+    """B operands of `bmm`, packed once into the GEMM's fragment-major weight planes: fp32 [batch, N, K] (contiguous; `awt_bmm_pack`), or with
+    `kmajor=((t1, off1), (t2, off2) | None, K1, ld, stride, batch, N, K)` the operand given transposed in memory, B_z[n, k] =
+    (k < K1 ? t1 : t2)[off + z stride + (k | k - K1) ld + n] (`awt_bmm_pack_kmajor`)."""
+
+    def __init__(self, b: Optional[torch.Tensor] = None, kmajor=None):
+        L = _lib.lib()
+        if kmajor is None:
+            b = b.detach().float().contiguous()
+            self.batch, self.N, self.K = b.shape
+            dev = b.device
+        else:
+            (t1, o1), second, K1, ld, stride, self.batch, self.N, self.K = kmajor
+            dev = t1.device
+        nbytes = int(L.awt_bmm_packed_bytes(self.batch, self.N, self.K))
+        self.buf = _lib.workspace(nbytes, dev)
+        with torch.cuda.device(dev):
+            if kmajor is None:
+                _lib.check(L.awt_bmm_pack(_lib.ctx(dev), _lib.ptr(b), self.K, self.N * self.K, self.batch, self.N, self.K, _lib.ptr(self.buf), self.buf.numel(),
+                                          _lib.stream_handle()))
+            else:
+                p2 = None if second is None else second[0].data_ptr() + 4 * second[1]
+                _lib.check(L.awt_bmm_pack_kmajor(_lib.ctx(dev), t1.data_ptr() + 4 * o1, p2, K1, ld, stride, self.batch, self.N, self.K, _lib.ptr(self.buf),
+                                                 self.buf.numel(), _lib.stream_handle()))
+
+
+def bmm(a, pb: PackedBatch, M: int, out, resid=None, a_kmajor=None) -> None:
+    """out_z [M, N] = a_z [M, K] B_z^T (+ resid_z) for z < pb.batch.  `a`, `out`, `resid`: (tensor, element offset, row pitch, matrix stride) views
+    of row-major fp32 storage (`resid` shares the output's pitch / stride and may be the output itself).  `a_kmajor=((t1, off1), (t2, off2) | None,
+    K1, ld, stride)` instead of `a`: the left operand given transposed in memory, optionally as two matrices stacked along K (as PackedBatch)."""
+    ot, oo, ldo, so = out
+    dev = ot.device
+    L = _lib.lib()
+    ws = _lib.workspace(L.awt_bmm_workspace_bytes(pb.batch, M, pb.K), dev)
+    rp = None
+    if resid is not None:
+        rt, ro, ldr, sr = resid
+        if (ldr, sr) != (ldo, so):
+            raise ValueError("bmm: the residual must have the output's pitch and stride")
+        rp = rt.data_ptr() + 4 * ro
+    with torch.cuda.device(dev):
+        if a_kmajor is None:
+            at, ao, lda, sa = a
+            _lib.check(L.awt_bmm(_lib.ctx(dev), at.data_ptr() + 4 * ao, lda, sa, _lib.ptr(pb.buf), rp, ot.data_ptr() + 4 * oo, ldo, so, pb.batch, M, pb.N, pb.K,
+                                 _lib.ptr(ws), ws.numel(), _lib.stream_handle()))
+        else:
+            (t1, o1), second, K1, lda, sa = a_kmajor
+            p2 = None if second is None else second[0].data_ptr() + 4 * second[1]
+            _lib.check(L.awt_bmm_kmajor(_lib.ctx(dev), t1.data_ptr() + 4 * o1, p2, K1, lda, sa, _lib.ptr(pb.buf), rp, ot.data_ptr() + 4 * oo, ldo, so, pb.batch,
+                                        M, pb.N, pb.K, _lib.ptr(ws), ws.numel(), _lib.stream_handle()))
+
+
+def softmax_rows(s: torch.Tensor, cols: int, scale: float) -> torch.Tensor:
+    """In place: rows of the 2-D view [rows, ld] -> softmax(scale * row[:cols])."""
+    rows, ld = s.shape
+    with torch.cuda.device(s.device):
+        _lib.check(_lib.lib().awt_op_softmax_rows(_ctx(s), _lib.ptr(s), _lib.ptr(s), rows, cols, ld, scale, _lib.stream_handle()))
+    return s
+
+
+def softmax_rows_backward(p: torch.Tensor, dp: torch.Tensor, cols: int, scale: float) -> torch.Tensor:
+    """In place on dp: scale * p * (dp - rowsum(p dp))."""
+    rows, ld = p.shape
+    with torch.cuda.device(p.device):
+        _lib.check(_lib.lib().awt_op_softmax_rows_backward(_ctx(p), _lib.ptr(p), _lib.ptr(dp), _lib.ptr(dp), rows, cols, ld, scale, _lib.stream_handle()))
+    return dp
+
+
+class _AbsorbedCross:
+    """One step's cross-attention over the encoder states `enc` [B, S, d] with the key / value projections moved to the query side (module
+    docstring).  Rows of the per-clip matrices are ordered r = l * H + h, so that [B L, H, d] storage is at once `H` strided per-head matrices
+    (pitch H d, stride d) and `B` per-clip matrices [L H, d].  HF:modeling_whisper.py:284-356."""
+
+    ROW_LIMIT = 512          # H L above which the projected keys / values (cross_kv) are the cheaper form: 6 H L > 4 d
+
+    def __init__(self, dec: "NativeWhisperDecoder", enc: torch.Tensor):
+        self.dec = dec
+        self.B, self.S, self.d = enc.shape
+        self.Sp = (self.S + 3) // 4 * 4
+        self.enc_p = PackedBatch(enc)                                           # B operand [S, d] of scores and dP
+        self.encT_p = PackedBatch(enc.transpose(1, 2))                          # B operand [d, S] of the context and d(q~)
+        self.eff: Dict[int, dict] = {}
+
+    def _heads(self, i: int) -> dict:
+        """Per-head blocks of layer i's key / value projections as batched B operands; with a value adapter the merged weight
+        W_v + (alpha / r) B A of this step (the adapter's gradient comes back through d(merged weight), `backward`)."""
+        dec, H, d = self.dec, self.dec.heads, self.d
+        pk = dec.packed()["cross_heads"][i]
+        ab = dec._adapter(i, "encoder_attn", "v_proj")
+        if ab is None:
+            return pk
+        if i not in self.eff:
+            A, Bm = ab
+            wv = dec.layers[i].encoder_attn.v_proj.weight.detach() + gemm(Bm.detach(), A.detach().t().contiguous(), dec.precision) * dec.lora.scale
+            self.eff[i] = dict(pk, v=PackedBatch(wv.view(H, 64, d)), vT=PackedBatch(wv.view(H, 64, d).transpose(1, 2)))
+        return self.eff[i]
+
+    def attend(self, i: int, q: torch.Tensor, L: int):
+        """q [B L, d] (bias and adapter applied, unscaled) -> (attention output [B L, d] before out_proj, what `backward` needs)."""
+        B, S, Sp, d, H = self.B, self.S, self.Sp, self.d, self.dec.heads
+        R, M = L * H, B * L
+        hw = self._heads(i)
+        dev = q.device
+        qt = torch.empty((M, H, d), dtype=torch.float32, device=dev)
+        bmm((q, 0, d, 64), hw["kT"], M, (qt, 0, H * d, d))                                      # q~_h = q_h W_k,h
+        P = torch.empty((B * R, Sp), dtype=torch.float32, device=dev)
+        bmm((qt, 0, d, R * d), self.enc_p, R, (P, 0, Sp, R * Sp))                                # scores = q~ enc^T
+        softmax_rows(P, S, 0.125)
+        c = torch.empty((M, H, d), dtype=torch.float32, device=dev)
+        bmm((P, 0, Sp, R * Sp), self.encT_p, R, (c, 0, d, R * d))                                # context = P enc
+        a2 = torch.empty((M, d), dtype=torch.float32, device=dev)
+        bmm((c, 0, H * d, d), hw["v"], M, (a2, 0, d, 64))                                        # (P enc) W_v,h^T
+        a2 += self.dec.layers[i].encoder_attn.v_proj.bias                                       # rows of P sum to one
+        return a2, (qt, P, c)
+
+    def backward(self, i: int, saved, da2: torch.Tensor, d_enc: torch.Tensor, L: int, grads: dict) -> torch.Tensor:
+        """Adds this layer's share of d(loss) / d(encoder states) to `d_enc` [B, S, d]; returns dq [B L, d]."""
+        B, S, Sp, d, H = self.B, self.S, self.Sp, self.d, self.dec.heads
+        R, M = L * H, B * L
+        qt, P, c = saved
+        hw = self._heads(i)
+        dev = da2.device
+        da2 = da2.contiguous()
+        dc = torch.empty((M, H, d), dtype=torch.float32, device=dev)
+        bmm((da2, 0, d, 64), hw["vT"], M, (dc, 0, H * d, d))                                     # d(context)_h = da2_h W_v,h
+        dS = torch.empty((B * R, Sp), dtype=torch.float32, device=dev)
+        bmm((dc, 0, d, R * d), self.enc_p, R, (dS, 0, Sp, R * Sp))                               # dP = d(context) enc^T
+        softmax_rows_backward(P, dS, S, 0.125)
+        dqt = torch.empty((M, H, d), dtype=torch.float32, device=dev)
+        bmm((dS, 0, Sp, R * Sp), self.encT_p, R, (dqt, 0, d, R * d))                             # d(q~) = dS enc
+        # d(enc)_b += P_b^T d(context)_b + dS_b^T q~_b : one [S, 2 R] x [2 R, d] product per clip
+        # (all four matrices are read where they lie: both operands are K-major, two blocks stacked along K)
+        rhs = PackedBatch(kmajor=((dc, 0), (qt, 0), R, d, R * d, B, d, 2 * R))                   # B operand [d, 2 R] = [d(context)_b ; q~_b]^T
+        bmm(None, rhs, S, (d_enc, 0, d, S * d), resid=(d_enc, 0, d, S * d), a_kmajor=((P, 0), (dS, 0), R, Sp, R * Sp))
+        dq = torch.empty((M, d), dtype=torch.float32, device=dev)
+        bmm((dqt, 0, H * d, d), hw["k"], M, (dq, 0, d, 64))                                      # dq_h = d(q~)_h W_k,h^T
+        ab = self.dec._adapter(i, "encoder_attn", "v_proj")
+        if ab is not None:                                                                       # d(merged W_v)_h = da2_h^T context_h, then through W_v + s B A
+            A, Bm = ab
+            dw = torch.empty((d, d), dtype=torch.float32, device=dev)
+            bmm(None, PackedBatch(kmajor=((c, 0), None, M, H * d, d, H, d, M)), 64, (dw, 0, d, 64 * d), a_kmajor=((da2, 0), None, M, d, 64))
+            scale, prec = self.dec.lora.scale, self.dec.precision
+            grads[id(Bm)] = gemm(dw, A.detach(), prec) * scale                                   # dB [d, r] = s dW A^T
+            grads[id(A)] = gemm(Bm.detach().t().contiguous(), dw.t().contiguous(), prec) * scale  # dA [r, d] = s B^T dW
+        return dq
+
+
 def cross_entropy(logits, labels, vocab):
     """(loss scalar tensor, dlogits [M, ld]) of CrossEntropyLoss(ignore_index=-100) over the first `vocab` columns."""
     M, ld = logits.shape
@@ -221,6 +375,18 @@ class NativeWhisperDecoder(nn.Module):
                         leaf.lora_B = nn.Parameter(torch.zeros(d, lora.r), requires_grad=True)          # B = 0: the adapter starts inert
         self._packed: Optional[Dict[str, object]] = None
         self._versions: Optional[Tuple[int, ...]] = None
+        import os
+        self.cross_mode = os.environ.get("AWT_DECODER_CROSS", "auto")          # "auto" | "kv" | "absorbed" (A/B runs: tools, bench)
+        if self.cross_mode not in ("auto", "kv", "absorbed"):
+            raise ValueError("AWT_DECODER_CROSS must be auto, kv or absorbed")
+
+    def absorbed_cross(self, L: int, S: int) -> bool:
+        """Whether the training step's cross-attention takes the absorbed form (`cross_mode`: "auto" = by the row count H L, "kv", "absorbed")."""
+        if self.cross_mode == "auto":
+            return self.heads * L <= _AbsorbedCross.ROW_LIMIT and S % 4 == 0 and S <= 4096
+        if self.cross_mode == "absorbed" and (S % 4 != 0 or S > 4096):
+            raise ValueError("absorbed cross-attention needs a multiple of 4 and at most 4096 encoder positions")
+        return self.cross_mode == "absorbed"
 
     # ------------------------------------------------------------------------------------------------ adapters
     def lora_parameters(self) -> List[nn.Parameter]:
@@ -292,6 +458,11 @@ class NativeWhisperDecoder(nn.Module):
         pk["ckv"] = PackedLinear(torch.cat([w for a in att for w in (a.k_proj.weight, a.v_proj.weight)]),
                                  torch.cat([b for a in att for b in (zeros, a.v_proj.bias)]), prec)
         pk["vocab"] = PackedLinear(self.embed_tokens.weight, None, prec)
+        H, d = self.heads, self.d
+        pk["cross_heads"] = []                                                     # per-head blocks of W_k / W_v as batched B operands (_AbsorbedCross)
+        for a in att:
+            wk, wv = a.k_proj.weight.detach().view(H, 64, d), a.v_proj.weight.detach().view(H, 64, d)
+            pk["cross_heads"].append({"k": PackedBatch(wk), "kT": PackedBatch(wk.transpose(1, 2)), "v": PackedBatch(wv), "vT": PackedBatch(wv.transpose(1, 2))})
         self._packed, self._versions = pk, vers
         return pk
 
@@ -314,7 +485,8 @@ class NativeWhisperDecoder(nn.Module):
         return x
 
     def _run(self, ids: torch.Tensor, kv: torch.Tensor, S: int, save: Optional[list], caches=None, position_offset: int = 0) -> torch.Tensor:
-        """Token ids [B, L] + cross keys / values -> final-LayerNorm input x [B * L, d] (saving what the backward needs in `save`)."""
+        """Token ids [B, L] + cross keys / values (the `cross_kv` tensor, or an `_AbsorbedCross` over the encoder states) -> final-LayerNorm
+        input x [B * L, d] (saving what the backward needs in `save`)."""
         pk = self.packed()
         B, L = ids.shape
         d, H, nl = self.d, self.heads, self.n_layers
@@ -343,7 +515,10 @@ class NativeWhisperDecoder(nn.Module):
             if ab is not None:
                 us["cq"], delta = self._lora_term(h2, ab)
                 q += delta
-            a2, lse2 = attention_small((q, 0), d, (kv, 2 * i * d), 2 * nl * d, (kv, (2 * i + 1) * d), 2 * nl * d, B, H, L, S, False, 0, save is not None)
+            if isinstance(kv, _AbsorbedCross):
+                a2, lse2 = kv.attend(i, q, L)                                            # lse2: (q~, P, context) for the backward
+            else:
+                a2, lse2 = attention_small((q, 0), d, (kv, 2 * i * d), 2 * nl * d, (kv, (2 * i + 1) * d), 2 * nl * d, B, H, L, S, False, 0, save is not None)
             x2 = p["co"].forward(a2, resid=x1)
             h3 = layernorm(x2, lay.final_layer_norm.weight, lay.final_layer_norm.bias)
             f = p["fc1"].forward(h3)
@@ -380,8 +555,11 @@ class _DecoderLoss(torch.autograd.Function):
         B, S, d = enc.shape
         L = ids.shape[1]
         enc2d = enc.reshape(B * S, d).float().contiguous()
-        kv = dec.packed()["ckv"].forward(enc2d)
-        u_cv = dec._cross_v_adapters(enc2d, kv)
+        if dec.absorbed_cross(L, S):
+            kv, u_cv = _AbsorbedCross(dec, enc2d.view(B, S, d)), None
+        else:
+            kv = dec.packed()["ckv"].forward(enc2d)
+            u_cv = dec._cross_v_adapters(enc2d, kv)
         save: list = []
         x = dec._run(ids, kv, S, save)
         xf = layernorm(x, dec.layer_norm.weight, dec.layer_norm.bias)
@@ -411,7 +589,11 @@ class _DecoderLoss(torch.autograd.Function):
 
         dlogits = ctx.dlogits * g                                                           # upstream scalar (1 / micro-batches, ...)
         dx = layernorm_backward(pk["vocab"].backward_input(dlogits), ctx.x_last, dec.layer_norm.weight)
-        dkv = torch.empty_like(kv)                                                          # every layer writes its own two d-wide blocks
+        absorbed = isinstance(kv, _AbsorbedCross)
+        if absorbed:
+            d_enc = torch.zeros((B, S, d), dtype=torch.float32, device=dx.device)           # every layer adds its share (one batched GEMM each)
+        else:
+            dkv = torch.empty_like(kv)                                                      # every layer writes its own two d-wide blocks
         for i in range(nl - 1, -1, -1):
             lay, p = dec.layers[i], pk["layers"][i]
             x0, qkv, a, lse, x1, q, a2, lse2, x2, f, us = save[i]
@@ -420,9 +602,12 @@ class _DecoderLoss(torch.autograd.Function):
             dx = layernorm_backward(p["fc1"].backward_input(df), x2, lay.final_layer_norm.weight, dres=dx)
             # cross-attention: x2 = x1 + out(attn(q(LN2(x1)), K_i, V_i))
             da2 = p["co"].backward_input(dx)
-            dq = torch.empty_like(q)
-            attention_small_backward((q, 0), d, (kv, 2 * i * d), 2 * nl * d, (kv, (2 * i + 1) * d), 2 * nl * d, a2, da2, lse2,
-                                     (dq, 0), (dkv, 2 * i * d), (dkv, (2 * i + 1) * d), B, H, L, S, False, 0)
+            if absorbed:
+                dq = kv.backward(i, lse2, da2, d_enc, L, grads)
+            else:
+                dq = torch.empty_like(q)
+                attention_small_backward((q, 0), d, (kv, 2 * i * d), 2 * nl * d, (kv, (2 * i + 1) * d), 2 * nl * d, a2, da2, lse2,
+                                         (dq, 0), (dkv, 2 * i * d), (dkv, (2 * i + 1) * d), B, H, L, S, False, 0)
             dh2 = p["cq"].backward_input(dq)
             ab = dec._adapter(i, "encoder_attn", "q_proj")
             if ab is not None:
@@ -445,7 +630,8 @@ class _DecoderLoss(torch.autograd.Function):
                         dh = dh + adapter_backward(ab, h, us[proj], dqkv[:, col: col + d].contiguous())
             dx = layernorm_backward(dh, x0, lay.self_attn_layer_norm.weight, dres=dx)
         ctx.saved = ctx.kv = ctx.dlogits = None
-        d_enc = pk["ckv"].backward_input(dkv)                                               # [B S, d]
+        if not absorbed:
+            d_enc = pk["ckv"].backward_input(dkv)                                           # [B S, d]
         if ctx.u_cv is not None:
             # cross-attention value adapters: dV_i = dkv block 2 i + 1 (B x S rows); their share of d(encoder states) is ONE GEMM over all layers
             r = dec.lora.r

@@ -97,6 +97,87 @@ def test_cross_entropy_gelu_layernorm_and_embedding_ops():
     assert (nd.layernorm_backward(dy, x, g, dres=dres).double() - (xd.grad + dres.double())).abs().max().item() < 1e-5
 
 
+@pytest.mark.parametrize("batch,M,N,K", [(3, 144, 1500, 768), (2, 144, 768, 1500), (5, 10, 64, 64), (2, 1500, 768, 288), (12, 20, 768, 64), (1, 257, 132, 70)])
+def test_batched_products_against_fp64(batch, M, N, K):
+    """awt_bmm / awt_bmm_pack (csrc/bmm.hip): C_z = A_z B_z^T on the MFMA GEMM, padded shapes, residual in place."""
+    from mlx8_ws_audio_transformer_amd import native_decoder as nd
+    a, b = _rand((batch, M, K), 1), _rand((batch, N, K), 2, K ** -0.5)
+    ref = a.double() @ b.double().transpose(1, 2)
+    tol = 3e-5 * max(1.0, ref.abs().max().item())
+    pb = nd.PackedBatch(b)
+    out = torch.full((batch, M, N), 7.0, device="cuda")
+    nd.bmm((a, 0, K, M * K), pb, M, (out, 0, N, M * N))
+    assert (out.double() - ref).abs().max().item() < tol
+    r0 = _rand((batch, M, N), 3)
+    acc = r0.clone()
+    nd.bmm((a, 0, K, M * K), pb, M, (acc, 0, N, M * N), resid=(acc, 0, N, M * N))
+    assert (acc.double() - (ref + r0.double())).abs().max().item() < tol
+
+
+def test_batched_products_on_strided_head_views():
+    """The per-head use: A_h = columns 64 h .. 64 h + 63 of a row-major [M, H 64] matrix, C_h written into rows (m, h) of [M, H, d] and back."""
+    from mlx8_ws_audio_transformer_amd import native_decoder as nd
+    M, H, d = 24, 3, 192
+    q, w = _rand((M, d), 1), _rand((d, d), 2, d ** -0.5)
+    wk = w.view(H, 64, d)
+    qt = torch.full((M, H, d), 7.0, device="cuda")
+    nd.bmm((q, 0, d, 64), nd.PackedBatch(wk.transpose(1, 2)), M, (qt, 0, H * d, d))
+    ref = torch.einsum("mhc,hcj->mhj", q.double().view(M, H, 64), wk.double())
+    assert (qt.double() - ref).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item())
+    back = torch.full((M, d), 7.0, device="cuda")
+    nd.bmm((qt, 0, H * d, d), nd.PackedBatch(wk), M, (back, 0, d, 64))
+    ref2 = torch.einsum("mhj,hcj->mhc", qt.double(), wk.double()).reshape(M, d)
+    assert (back.double() - ref2).abs().max().item() < 3e-5 * max(1.0, ref2.abs().max().item())
+
+
+def test_batched_products_with_k_major_operands():
+    """awt_bmm_kmajor / awt_bmm_pack_kmajor: both operands read transposed where they lie, each as two blocks stacked along K
+    (the backward's d(enc)_b = [P_b^T | dS_b^T] [d(context)_b ; q~_b])."""
+    from mlx8_ws_audio_transformer_amd import native_decoder as nd
+    B, R, S, Sp, d = 3, 20, 70, 72, 136
+    P, dS = _rand((B * R, Sp), 1), _rand((B * R, Sp), 2)
+    dc, qt = _rand((B * R, d), 3), _rand((B * R, d), 4)
+    acc0 = _rand((B, S, d), 5)
+    ref = acc0.double() + P.view(B, R, Sp)[:, :, :S].double().transpose(1, 2) @ dc.view(B, R, d).double() \
+        + dS.view(B, R, Sp)[:, :, :S].double().transpose(1, 2) @ qt.view(B, R, d).double()
+    rhs = nd.PackedBatch(kmajor=((dc, 0), (qt, 0), R, d, R * d, B, d, 2 * R))
+    acc = acc0.clone()
+    nd.bmm(None, rhs, S, (acc, 0, d, S * d), resid=(acc, 0, d, S * d), a_kmajor=((P, 0), (dS, 0), R, Sp, R * Sp))
+    assert (acc.double() - ref).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item())
+    # one block per side, strided per-head views (the value adapter's d(merged weight)_h = da2_h^T context_h)
+    M, H = 24, 2
+    da2, c = _rand((M, H * 64), 6), _rand((M, H, d), 7)
+    dw = torch.full((H * 64, d), 7.0, device="cuda")
+    nd.bmm(None, nd.PackedBatch(kmajor=((c, 0), None, M, H * d, d, H, d, M)), 64, (dw, 0, d, 64 * d), a_kmajor=((da2, 0), None, M, H * 64, 64))
+    ref2 = torch.einsum("mhc,mhj->hcj", da2.double().view(M, H, 64), c.double()).reshape(H * 64, d)
+    assert (dw.double() - ref2).abs().max().item() < 3e-5 * max(1.0, ref2.abs().max().item())
+
+
+@pytest.mark.parametrize("rows,cols,ld", [(7, 1500, 1500), (3, 70, 72), (2, 4096, 4096), (5, 1, 4)])
+def test_row_softmax_forward_and_backward(rows, cols, ld):
+    from mlx8_ws_audio_transformer_amd import native_decoder as nd
+    s = _rand((rows, ld), 1, 6.0)
+    dp = _rand((rows, ld), 2)
+    sd = s[:, :cols].double().requires_grad_(True)
+    ref = torch.softmax(sd * 0.125, -1)
+    ref.backward(dp[:, :cols].double())
+    p = nd.softmax_rows(s.clone(), cols, 0.125)
+    assert (p[:, :cols].double() - ref).abs().max().item() < 1e-6
+    assert torch.equal(p[:, cols:], s[:, cols:])                         # the padding columns are not touched
+    ds = nd.softmax_rows_backward(p, dp.clone(), cols, 0.125)
+    assert (ds[:, :cols].double() - sd.grad).abs().max().item() < 1e-6 * max(1.0, sd.grad.abs().max().item())
+
+
+def test_bmm_rejects_bad_arguments():
+    from mlx8_ws_audio_transformer_amd import native_decoder as nd
+    a, b = _rand((2, 8, 64), 1), _rand((2, 6, 64), 2)                       # N = 6: not a multiple of 4
+    out = torch.zeros((2, 8, 6), device="cuda")
+    with pytest.raises(RuntimeError, match="multiples of 4"):
+        nd.bmm((a, 0, 64, 8 * 64), nd.PackedBatch(b), 8, (out, 0, 6, 48))
+    with pytest.raises(RuntimeError, match="columns"):
+        nd.softmax_rows(torch.zeros((2, 5000), device="cuda"), 5000, 1.0)
+
+
 def _pair(native):
     """WhisperLoRAModel (mini encoder, 2 decoder layers, vocab 512) with the deterministic weights of tests/golden/decoder.npz."""
     from mlx8_ws_audio_transformer_amd.finetune import WhisperLoRAModel
@@ -124,20 +205,25 @@ def test_native_decoder_loss_logits_and_greedy_tokens_match_reference():
     np.testing.assert_array_equal(ids, G["greedy_ids"])
 
 
-def test_native_decoder_gradients_match_the_torch_decoder():
-    """Adapter gradients of the full step (native encoder backward fed by d(loss)/d(hidden)): native decoder vs stock-PyTorch decoder."""
+@pytest.mark.parametrize("cross_mode", ["kv", "absorbed"])
+def test_native_decoder_gradients_match_the_torch_decoder(cross_mode):
+    """Adapter gradients of the full step (native encoder backward fed by d(loss)/d(hidden)): native decoder vs stock-PyTorch decoder, with the
+    cross-attention on projected keys / values ("kv") and in the absorbed form the training step uses for short label sequences."""
     G = golden("decoder.npz")
     labels = torch.from_numpy(G["labels"]).cuda()
     res = {}
     for native in (False, True):
         model, mel = _pair(native)
+        if native:
+            model.decoder.cross_mode = cross_mode
+            assert model.decoder.absorbed_cross(labels.shape[1], model.encoder.cfg.max_source_positions) == (cross_mode == "absorbed")
         with torch.no_grad():
             for p in model.lora_parameters():
                 if p.shape[1] == 8:
                     p.copy_(torch.from_numpy(0.05 * wts.unit_variates("ndec", p.numel(), 1).reshape(p.shape).astype(np.float32)))
         out = model(input_features=mel, labels=labels)
         out.loss.backward()
-        res[native] = (float(out.loss.detach()), torch.cat([p.grad.flatten() for p in model.lora_parameters()]).cpu(), out.logits.float().cpu())
+        res[native] = (float(out.loss.detach()), torch.cat([p.grad.flatten() for p in model.lora_parameters()]).cpu(), out.logits.detach().float().cpu())
     assert abs(res[True][0] - res[False][0]) < 2e-4 * abs(res[False][0])
     assert float((res[True][2] - res[False][2]).abs().max()) < 2e-3
     ref = res[False][1]
@@ -180,8 +266,9 @@ class _TorchLoRALinear(torch.nn.Module):
         return self.base(x) + self.scale * F.linear(F.linear(x, self.A), self.B)
 
 
+@pytest.mark.parametrize("cross_mode", ["kv", "absorbed"])
 @pytest.mark.parametrize("targets", [("q_proj", "v_proj"), ("v_proj",)])
-def test_decoder_adapters_forward_and_gradients_match_torch_autograd(targets):
+def test_decoder_adapters_forward_and_gradients_match_torch_autograd(targets, cross_mode):
     """Scope row f1, second half ("+ LoRA on decoder"; the reference fine-tunes every decoder parameter, AB/fineTune.py:131,186-199):
     adapters on the decoder's self-attention and cross-attention q_proj / v_proj.  Loss, logits, d(loss)/d(encoder adapters) and
     d(loss)/d(every decoder adapter) of the native path against torch autograd over the stock-PyTorch decoder carrying the same adapters."""
@@ -207,6 +294,7 @@ def test_decoder_adapters_forward_and_gradients_match_torch_autograd(targets):
         return m
 
     nat = build(True)
+    nat.decoder.cross_mode = cross_mode
     names = [n for n, _ in nat.decoder.named_parameters() if "lora_" in n]
     assert len(names) == 2 * 2 * len(targets) * 2 and all(p.requires_grad for n, p in nat.decoder.named_parameters() if "lora_" in n)
     assert not any(p.requires_grad for n, p in nat.decoder.named_parameters() if "lora_" not in n)
