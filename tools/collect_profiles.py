@@ -13,7 +13,7 @@ entries = []
 for tag in tags:
     src = os.path.join(ROOT, "gpurun_out", tag)
     suffix = tag.split(rnd + "_", 1)[-1] if rnd + "_" in tag else tag
-    for name in ("kernel_stats.csv", "mfma.json", "traffic.json"):
+    for name in ("kernel_stats.csv", "mfma.json", "traffic.json", "fabric.json"):
         p = os.path.join(src, name)
         if os.path.exists(p):
             base, ext = os.path.splitext(name)

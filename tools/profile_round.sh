@@ -14,6 +14,40 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 # MFMA utilisation and effective clock (own pass; SQ + GRBM slots)
 timeout -k 10 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_MFMA -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-fast-mode --no-power --precision $prec --weights $wts > $out/pmc_MFMA.log 2>&1
+# Fabric side of the L2 (own passes): average L2 -> fabric read latency, cycles stalled for DRAM credits, L2 hit rate.  rocprofv3 on gfx950 exposes no
+# Infinity-Cache (MALL) or UMC counter, so "fetched from HBM" vs "served by the Infinity Cache" cannot be split from here: TCC_EA0_RDREQ_DRAM counts both.
+timeout -k 10 600 rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_LEVEL_sum TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum TCC_CYCLE_sum --output-format csv -d $out/pmc_FABRIC -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-fast-mode --no-power --precision $prec --weights $wts > $out/pmc_FABRIC.log 2>&1
+timeout -k 10 600 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d $out/pmc_L2 -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-fast-mode --no-power --precision $prec --weights $wts > $out/pmc_L2.log 2>&1
+python3 - $out $tag $prec $wts <<'PY3'
+import csv, glob, json, sys, collections
+out, tag = sys.argv[1], sys.argv[2]
+sys.path.insert(0, "."); import bench
+def short(n):
+    for k, pats in (("gemm_kernel", ("gemm_kernel", "gemm_f8_kernel")), ("attention_kernel", ("attention_kernel", "attention_f16f8")), ("layernorm_kernel", ("layernorm_kernel",))):
+        if any(p in n for p in pats): return k
+acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
+for d in ("pmc_FABRIC", "pmc_L2"):
+    cc = glob.glob(f"{out}/{d}/**/*counter_collection.csv", recursive=True)
+    if not cc: continue
+    seen = set()
+    for r in csv.DictReader(open(cc[0])):
+        k = short(r["Kernel_Name"])
+        if not k: continue
+        acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        if d == "pmc_FABRIC" and r["Dispatch_Id"] not in seen:
+            seen.add(r["Dispatch_Id"]); n[k] += 1
+res = {}
+for k, c in acc.items():
+    rd, lvl, cyc = c.get("TCC_EA0_RDREQ_sum", 0.0), c.get("TCC_EA0_RDREQ_LEVEL_sum", 0.0), c.get("TCC_CYCLE_sum", 0.0)
+    res[k] = {"launches_counted": n[k], "ea_read_requests_per_launch": rd / max(n[k], 1), "ea_read_requests_to_dram_frac": c.get("TCC_EA0_RDREQ_DRAM_sum", 0.0) / rd if rd else None,
+              "avg_ea_read_latency_l2_cycles": lvl / rd if rd else None,
+              "dram_credit_stall_frac_of_tcc_cycles": c.get("TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum", 0.0) / cyc if cyc else None,
+              "l2_hit_rate": c.get("TCC_HIT_sum", 0.0) / (c.get("TCC_HIT_sum", 0.0) + c.get("TCC_MISS_sum", 0.0)) if (c.get("TCC_HIT_sum", 0.0) + c.get("TCC_MISS_sum", 0.0)) else None}
+json.dump({"tag": tag, "build": bench.source_hash(), "precision": sys.argv[3], "weights": sys.argv[4],
+           "note": "L2 (TCC) fabric interface; no MALL / UMC counters are exposed on gfx950, so HBM vs Infinity-Cache reads cannot be separated: RDREQ_DRAM counts requests to the memory side (both)",
+           "per_kernel": res}, open(f"{out}/fabric.json", "w"), indent=1)
+print(json.dumps(res, indent=1))
+PY3
 python3 - $out $tag $prec $wts <<'PY2'
 import csv, glob, json, sys, collections
 out, tag = sys.argv[1], sys.argv[2]
