@@ -1,6 +1,10 @@
 // HBM-bound row kernels of the encoder: LayerNorm (K8), fp32 -> split-bf16 planes, weight packing, conv1 im2col.
 #include "common.h"
 
+#ifndef AWT_LN_NT_LOAD
+#define AWT_LN_NT_LOAD 1   // -0.3 .. -0.4 ms per encoder step, most of it in the GEMM that follows (profiles/r03_gemm_experiments.txt)
+#endif
+
 namespace {
 
 // ------------------------------------------------------------------------------------------------ LayerNorm
@@ -23,7 +27,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 #pragma unroll
   for (int i = 0; i < kLnMaxChunks; ++i) {
     const int c = lane + 64 * i;
+#if AWT_LN_NT_LOAD   // the residual stream is read once here: a streaming load keeps the planes this kernel writes (the next GEMM's operand) cache-resident
+    if (c < nchunk) { const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xr + c)); v[i] = make_float4(t[0], t[1], t[2], t[3]); }
+    else v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#else
     v[i] = c < nchunk ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
     sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
   }
 #pragma unroll
@@ -160,6 +169,18 @@ __global__ __launch_bounds__(256) void im2col_conv1_kernel(const float* __restri
 // ------------------------------------------------------------------------------------------------ LayerNorm backward
 // dx = dres + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma,  xhat = (x - mean) * rstd.
 // Statistics are recomputed from the saved LayerNorm input (fp32), one wave per row, row in registers.
+#ifndef AWT_LNB_NT_LOAD
+#define AWT_LNB_NT_LOAD 1   // LayerNorm class of the fine-tune step 8.94 -> 8.45 ms (profiles/r03_gemm_experiments.txt)
+#endif
+// a 16-byte load of data this kernel reads exactly once (streaming when AWT_LNB_NT_LOAD)
+__device__ __forceinline__ float4 ldg_once(const float4* p) {
+#if AWT_LNB_NT_LOAD
+  const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+  return make_float4(t[0], t[1], t[2], t[3]);
+#else
+  return *p;
+#endif
+}
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ gamma, const float* dres, int M, int d,
                                                             float eps, float* dx, bf16_t* dx_hi, bf16_t* dx_lo) {
@@ -175,7 +196,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 #pragma unroll
   for (int i = 0; i < kLnMaxChunks; ++i) {
     const int c = lane + 64 * i;
-    v[i] = c < nchunk ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    v[i] = c < nchunk ? ldg_once(xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
   }
 #pragma unroll
@@ -199,7 +220,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     const int c = lane + 64 * i;
     g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (c < nchunk) {
-      const float4 gy = dyr[c], gm = g4[c];
+      const float4 gy = ldg_once(dyr + c), gm = g4[c];
       v[i].x *= rstd; v[i].y *= rstd; v[i].z *= rstd; v[i].w *= rstd;        // xhat
       g[i] = make_float4(gy.x * gm.x, gy.y * gm.y, gy.z * gm.z, gy.w * gm.w);
       s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
@@ -216,7 +237,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     float y[4] = {rstd * (g[i].x - c1 - v[i].x * c2), rstd * (g[i].y - c1 - v[i].y * c2),
                   rstd * (g[i].z - c1 - v[i].z * c2), rstd * (g[i].w - c1 - v[i].w * c2)};
     if (dres) {
-      const float4 r = reinterpret_cast<const float4*>(dres + (int64_t)row * d)[c];
+      const float4 r = ldg_once(reinterpret_cast<const float4*>(dres + (int64_t)row * d) + c);
       y[0] += r.x; y[1] += r.y; y[2] += r.z; y[3] += r.w;
     }
     reinterpret_cast<float4*>(dx + (int64_t)row * d)[c] = make_float4(y[0], y[1], y[2], y[3]);

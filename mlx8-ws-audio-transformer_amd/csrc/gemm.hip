@@ -33,6 +33,9 @@
 
 namespace {
 
+#ifndef AWT_GEMM_NT_STORE
+#define AWT_GEMM_NT_STORE 1   // f16f8 kernel: operand-plane outputs leave as streaming (non-temporal) stores: whole 256-byte row segments per instruction, read next by
+#endif                        // another kernel; -0.3 ms per step.  (NOT for the 4 / 8-byte stores of attention / LayerNorm: those need L2 write combining, +60 % there.)
 #ifndef AWT_GEMM_WDEC
 #define AWT_GEMM_WDEC 1   // f16f8 kernel: the K-tile barrier waits for the LDS-DMA only; W fragment loads are waited for at their consumers
 #endif
@@ -293,10 +296,17 @@ __device__ __forceinline__ void store_out8_f8(const GemmOut& o, int m, int n, fl
 #ifdef AWT_DIAG_NO_STORE   // timing-only: every store instruction stays, but all waves write the same 1 KB per plane (L2-resident: no HBM write traffic)
   off = (threadIdx.x & 63) * 8;
 #endif
+#if AWT_GEMM_NT_STORE   // the planes are read next by another kernel, not by this one -> streaming stores (profiles/r03_gemm_experiments.txt)
+  __builtin_nontemporal_store((i32x4_t){(int)pack2(h[0], h[1]), (int)pack2(h[2], h[3]), (int)pack2(h[4], h[5]), (int)pack2(h[6], h[7])}, reinterpret_cast<i32x4_t*>(o.hi + off));
+  if (EPI == EPI_QKV && o.skip_v8 && n >= 2 * o.H * 64) return;
+  if (o.hi8) __builtin_nontemporal_store((i32x2){(int)fp8x4_rt(v[0], v[1], v[2], v[3], lim8, inv8), (int)fp8x4_rt(v[4], v[5], v[6], v[7], lim8, inv8)}, reinterpret_cast<i32x2*>(o.hi8 + off));
+  __builtin_nontemporal_store((i32x2){(int)fp8x4_rt(l[0], l[1], l[2], l[3], liml8, invl8), (int)fp8x4_rt(l[4], l[5], l[6], l[7], liml8, invl8)}, reinterpret_cast<i32x2*>(o.lo8 + off));
+#else
   *reinterpret_cast<uint4*>(o.hi + off) = make_uint4(pack2(h[0], h[1]), pack2(h[2], h[3]), pack2(h[4], h[5]), pack2(h[6], h[7]));
   if (EPI == EPI_QKV && o.skip_v8 && n >= 2 * o.H * 64) return;      // v: fp16 plane only
   if (o.hi8) *reinterpret_cast<uint2*>(o.hi8 + off) = make_uint2(fp8x4_rt(v[0], v[1], v[2], v[3], lim8, inv8), fp8x4_rt(v[4], v[5], v[6], v[7], lim8, inv8));   // null: see store_act4
   *reinterpret_cast<uint2*>(o.lo8 + off) = make_uint2(fp8x4_rt(l[0], l[1], l[2], l[3], liml8, invl8), fp8x4_rt(l[4], l[5], l[6], l[7], liml8, invl8));
+#endif
 }
 
 template <int TERMS, int BK, int EPI, class CFG, bool F16, bool WX = false, bool BATCH = false>
