@@ -8,16 +8,24 @@ prec=${2:-f16f8}
 wts=${3:-fp32}
 out=gpurun_out/prof_$tag; rm -rf $out; mkdir -p $out
 args="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fast-mode --no-power --precision $prec --weights $wts"
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $args > $out/trace.log 2>&1
-for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc_$c -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-fast-mode --no-power --precision $prec --weights $wts > $out/pmc_$c.log 2>&1
-done
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $args > $out/trace.log 2>&1 || { echo "kernel-trace pass failed"; exit 1; }
+echo "pass trace done"
+pmc_pass() {   # <dir> <counters...>: one --pmc pass of a 1-step bench; a failed pass ends the script (no further GPU step after a failure)
+  local d=$1; shift
+  timeout -k 10 240 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $out/$d -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-fast-mode --no-power --precision $prec --weights $wts > $out/$d.log 2>&1 || { echo "pass $d failed"; tail -3 $out/$d.log | cut -c1-300; exit 1; }
+  echo "pass $d done"
+}
+pmc_pass pmc_FETCH_SIZE FETCH_SIZE
+pmc_pass pmc_WRITE_SIZE WRITE_SIZE
 # MFMA utilisation and effective clock (own pass; SQ + GRBM slots)
-timeout -k 10 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_MFMA -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-fast-mode --no-power --precision $prec --weights $wts > $out/pmc_MFMA.log 2>&1
+pmc_pass pmc_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE
 # Fabric side of the L2 (own passes): average L2 -> fabric read latency, cycles stalled for DRAM credits, L2 hit rate.  rocprofv3 on gfx950 exposes no
 # Infinity-Cache (MALL) or UMC counter, so "fetched from HBM" vs "served by the Infinity Cache" cannot be split from here: TCC_EA0_RDREQ_DRAM counts both.
-timeout -k 10 600 rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_LEVEL_sum TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum TCC_CYCLE_sum --output-format csv -d $out/pmc_FABRIC -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-fast-mode --no-power --precision $prec --weights $wts > $out/pmc_FABRIC.log 2>&1
-timeout -k 10 600 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d $out/pmc_L2 -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-fast-mode --no-power --precision $prec --weights $wts > $out/pmc_L2.log 2>&1
+# (at most two TCC counters per pass: five in one pass fail with "exceeds the capabilities of the hardware to collect")
+pmc_pass pmc_FABRIC_lat TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_LEVEL_sum
+pmc_pass pmc_FABRIC_dram TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum
+pmc_pass pmc_L2 TCC_HIT_sum TCC_MISS_sum
+pmc_pass pmc_L2cyc TCC_CYCLE_sum
 python3 - $out $tag $prec $wts <<'PY3'
 import csv, glob, json, sys, collections
 out, tag = sys.argv[1], sys.argv[2]
@@ -26,7 +34,7 @@ def short(n):
     for k, pats in (("gemm_kernel", ("gemm_kernel", "gemm_f8_kernel")), ("attention_kernel", ("attention_kernel", "attention_f16f8")), ("layernorm_kernel", ("layernorm_kernel",))):
         if any(p in n for p in pats): return k
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
-for d in ("pmc_FABRIC", "pmc_L2"):
+for d in ("pmc_FABRIC_lat", "pmc_FABRIC_dram", "pmc_L2", "pmc_L2cyc"):
     cc = glob.glob(f"{out}/{d}/**/*counter_collection.csv", recursive=True)
     if not cc: continue
     seen = set()
@@ -34,7 +42,7 @@ for d in ("pmc_FABRIC", "pmc_L2"):
         k = short(r["Kernel_Name"])
         if not k: continue
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
-        if d == "pmc_FABRIC" and r["Dispatch_Id"] not in seen:
+        if d == "pmc_FABRIC_lat" and r["Dispatch_Id"] not in seen:
             seen.add(r["Dispatch_Id"]); n[k] += 1
 res = {}
 for k, c in acc.items():
