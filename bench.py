@@ -77,7 +77,7 @@ def parse():
     ap.add_argument("--lora-r", type=int, default=8)
     ap.add_argument("--decoder-dtype", default="fp32", choices=["fp32", "bf16"], help="finetune workload with --torch-decoder: dtype of the stock-PyTorch decoder")
     ap.add_argument("--torch-decoder", action="store_true", help="finetune workload: stock-PyTorch decoder + CE instead of the native ones (A/B)")
-    ap.add_argument("--backward-precision", default=None, choices=["bf16"],
+    ap.add_argument("--backward-precision", default=None, choices=["bf16", "f16f8"],
                     help="finetune workload: gradient contractions in single bf16 products (opt-in; default = the forward's precision)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL, the real multi-GPU path) or gloo (rehearsal of the N > 1 code path on one GPU: every rank on cuda:0)")

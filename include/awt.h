@@ -124,7 +124,10 @@ typedef struct awt_encoder_cfg {
   int32_t backward_terms;   /* products of the backward pass' gradient contractions: 0 = mfma_terms (default: gradients
                                to 3e-5 of fp32 autograd), 1 with mfma_terms = 3 = one bf16 product (the usual
                                mixed-precision trade: ~0.5 % gradient error, 1.4x faster step); the attention scores are
-                               recomputed in split-bf16 either way                                            */
+                               recomputed in split-bf16 either way.  5 with mfma_terms = 3: the MLP's two backward GEMMs
+                               (d pre = (dx W2) gelu'(pre), d ln2 = d pre W1) run in the f16f8 operand format (2 instead of 3
+                               MFMA-equivalents, 2^-16 per operand like split-bf16), everything else in split-bf16; fp16 planes
+                               want gradients of order one: see awt_encoder_set_grad_scale_log2.  No fc1 / fc2 adapters.   */
 } awt_encoder_cfg;
 
 enum { AWT_LORA_Q = 1, AWT_LORA_K = 2, AWT_LORA_V = 4, AWT_LORA_OUT = 8, AWT_LORA_FC1 = 16, AWT_LORA_FC2 = 32 };
@@ -167,6 +170,10 @@ int awt_encoder_forward(awt_encoder* e, const float* input_features, int B, int 
  * enabled target in the order q_proj, k_proj, v_proj, out_proj, fc1, fc2: dA [r, in_features] then dB [out_features, r], row-major
  * (in / out = d_model except fc1: out = ffn_dim, fc2: in = ffn_dim).  Gradients of frozen weights and of the input features are
  * not produced (nothing below the first adapter needs them). */
+/* The backward pass carries 2^k x the gradient from the final LayerNorm on and divides the adapter gradients by 2^k on the way out (exact: powers of two).
+ * With backward_terms = 5 the host picks k so that the largest |d loss / d hidden| becomes ~2^6: fp16 planes hold gradients of order one at full precision,
+ * 1e-6 ones only as subnormals.  Default 0; any backward_terms accepts it. */
+int awt_encoder_set_grad_scale_log2(awt_encoder* e, int k);
 size_t awt_encoder_train_workspace_bytes(const awt_encoder* e, int B);
 size_t awt_encoder_lora_grad_count(const awt_encoder* e);
 int awt_encoder_forward_train(awt_encoder* e, const float* input_features, int B, int n_frames, float* last_hidden_state,

@@ -82,6 +82,7 @@ _SIGNATURES = {
     "awt_linear_workspace_bytes": (_sz, [_vp, _i, _i]),
     "awt_linear_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "awt_linear_backward_input": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
+    "awt_encoder_set_grad_scale_log2": (_i, [_vp, _i]),
     "awt_bmm_packed_bytes": (_sz, [_i, _i, _i]),
     "awt_bmm_pack": (_i, [_vp, _vp, _i64, _i64, _i, _i, _i, _vp, _sz, _vp]),
     "awt_bmm_workspace_bytes": (_sz, [_i, _i, _i]),

@@ -177,6 +177,7 @@ struct LoraGroup {   // adapters that share one input (q/k/v share LN1's output)
 struct Layer {
   Linear qkv, out, fc1, fc2;
   Planes qkvT, outT, fc1T, fc2T;   // training: transposed copies [K, N] of the frozen weights (dX = dY W)
+  Planes fc1T8, fc2T8;             // backward_terms = 5: the MLP's transposed copies in the f16f8 weight format (the MLP's two backward GEMMs run in it)
   float *ln1_g = nullptr, *ln1_b = nullptr, *ln2_g = nullptr, *ln2_b = nullptr;
   LoraGroup lq, lo_, l1, l2;
 };
@@ -202,6 +203,9 @@ struct awt_encoder {
   int chunk = 16;
   awt_comm* comm = nullptr;        // AWT_BWD_ALLREDUCE: adapter gradients are averaged over this communicator's ranks
   int comm_groups = 2;
+  bool mlp_f8 = false;             // cfg.backward_terms == 5: the MLP's backward GEMMs in f16f8 (the others in split-bf16)
+  float* wt_tmp = nullptr;         // [ffn_dim * d_model] fp32: W^T of the matrix being uploaded (packed into fc1T8 / fc2T8)
+  int grad_scale_log2 = 0;         // awt_encoder_set_grad_scale_log2: the backward pass carries 2^k x the gradient (fp16 planes), adapter gradients leave unscaled
 };
 
 namespace {
@@ -217,6 +221,13 @@ int alloc_planes(awt_encoder* e, Planes* pl, int64_t rows, int64_t ld) {
   int rc = dev_alloc(e, (void**)&pl->hi, (size_t)rows * ld * 2); if (rc) return rc;
   if (e->planes == 2) { rc = dev_alloc(e, (void**)&pl->lo, (size_t)rows * ld * 2); if (rc) return rc; }
   if (e->prec == PREC_F16F8) pl->x8 = (uint8_t*)pl->lo + (size_t)rows * ld;
+  return AWT_OK;
+}
+int alloc_planes_f8(awt_encoder* e, Planes* pl, int64_t rows, int64_t ld) {   // fp16 plane + the two e4m3 planes, whatever the forward precision
+  pl->rows = rows; pl->ld = ld;
+  int rc = dev_alloc(e, (void**)&pl->hi, (size_t)rows * ld * 2); if (rc) return rc;
+  rc = dev_alloc(e, (void**)&pl->lo, (size_t)rows * ld * 2); if (rc) return rc;
+  pl->x8 = (uint8_t*)pl->lo + (size_t)rows * ld;
   return AWT_OK;
 }
 int alloc_linear(awt_encoder* e, Linear* l, int N, int K) {
@@ -500,16 +511,20 @@ extern "C" int awt_encoder_create(awt_ctx* c, const awt_encoder_cfg* cfg, awt_en
               "encoder_create: mfma_terms must be 1 (bf16), 3 (bf16x3), 4 (fp16x3) or 5 (f16f8)");
   AWT_REQUIRE(!cfg->training || cfg->mfma_terms == PREC_BF16 || cfg->mfma_terms == PREC_BF16X3, AWT_ERR_INVALID,
               "encoder_create: training keeps its activations as bf16 planes: mfma_terms must be 1 or 3 (gradients do not fit fp16's range unscaled)");
-  AWT_REQUIRE(cfg->backward_terms == 0 || cfg->backward_terms == cfg->mfma_terms || (cfg->backward_terms == 1 && cfg->mfma_terms == 3), AWT_ERR_INVALID,
-              "encoder_create: backward_terms must be 0 (= mfma_terms), mfma_terms, or 1");
+  AWT_REQUIRE(cfg->backward_terms == 0 || cfg->backward_terms == cfg->mfma_terms || ((cfg->backward_terms == 1 || cfg->backward_terms == PREC_F16F8) && cfg->mfma_terms == 3),
+              AWT_ERR_INVALID, "encoder_create: backward_terms must be 0 (= mfma_terms), mfma_terms, 1, or 5 (f16f8 MLP backward) with mfma_terms = 3");
+  AWT_REQUIRE(cfg->backward_terms != PREC_F16F8 || (cfg->training && !(cfg->lora_targets & (AWT_LORA_FC1 | AWT_LORA_FC2))), AWT_ERR_INVALID,
+              "encoder_create: backward_terms = 5 runs the MLP's backward GEMMs in f16f8: training mode, and no adapters on fc1 / fc2");
   AWT_REQUIRE(cfg->lora_rank >= 0 && cfg->lora_rank <= 32, AWT_ERR_INVALID, "encoder_create: lora_rank must be in 0..32");
   AWT_REQUIRE(cfg->lora_rank == 0 || cfg->lora_targets != 0, AWT_ERR_INVALID, "encoder_create: lora_rank > 0 needs lora_targets");
   AWT_REQUIRE(!cfg->training || cfg->lora_rank > 0, AWT_ERR_INVALID, "encoder_create: training mode needs adapters (lora_rank > 0)");
   awt_encoder* e = new awt_encoder();
   e->ctx = c; e->cfg = *cfg; e->prec = cfg->mfma_terms; e->planes = cfg->mfma_terms == PREC_BF16 ? 1 : 2;
   e->chunk = cfg->chunk_clips > 0 ? cfg->chunk_clips : 64;
+  e->mlp_f8 = cfg->backward_terms == PREC_F16F8;
   const int d = cfg->d_model, f = cfg->ffn_dim;
   int rc = alloc_linear(e, &e->conv1, d, conv1_k(cfg->n_mels));
+  if (!rc && e->mlp_f8) rc = dev_alloc(e, (void**)&e->wt_tmp, (size_t)f * d * 4);
   if (!rc) rc = alloc_linear(e, &e->conv2, d, 3 * d);
   if (!rc) rc = dev_alloc(e, (void**)&e->pos, (size_t)cfg->n_ctx * d * 4);
   if (!rc) rc = dev_alloc(e, (void**)&e->lnf_g, (size_t)d * 4);
@@ -529,6 +544,8 @@ extern "C" int awt_encoder_create(awt_ctx* c, const awt_encoder_cfg* cfg, awt_en
       if (!rc) rc = alloc_planes(e, &L.outT, d, d);
       if (!rc) rc = alloc_planes(e, &L.fc1T, d, f);
       if (!rc) rc = alloc_planes(e, &L.fc2T, f, d);
+      if (!rc && e->mlp_f8) rc = alloc_planes_f8(e, &L.fc1T8, d, f);
+      if (!rc && e->mlp_f8) rc = alloc_planes_f8(e, &L.fc2T8, f, d);
     }
     float** lnp[4] = {&L.ln1_g, &L.ln1_b, &L.ln2_g, &L.ln2_b};
     for (int k = 0; k < 4 && !rc; ++k) rc = dev_alloc(e, (void**)lnp[k], (size_t)d * 4);
@@ -572,11 +589,11 @@ extern "C" int awt_encoder_set_weight(awt_encoder* e, const char* name, const fl
       return awt_fail(AWT_ERR_INVALID, std::string("set_weight: unknown parameter ") + name);
     Layer& L = e->layers[li];
     std::string rs(rest);
-    struct Proj { const char* key; Linear* lin; int row_off; int N; int K; LoraGroup* lg; int slot; uint32_t bit; Planes* wT; };
+    struct Proj { const char* key; Linear* lin; int row_off; int N; int K; LoraGroup* lg; int slot; uint32_t bit; Planes* wT; Planes* wT8; };
     Proj projs[] = {
-        {"self_attn.q_proj", &L.qkv, 0, d, d, &L.lq, 0, AWT_LORA_Q, &L.qkvT},   {"self_attn.k_proj", &L.qkv, d, d, d, &L.lq, 1, AWT_LORA_K, &L.qkvT},
-        {"self_attn.v_proj", &L.qkv, 2 * d, d, d, &L.lq, 2, AWT_LORA_V, &L.qkvT}, {"self_attn.out_proj", &L.out, 0, d, d, &L.lo_, 0, AWT_LORA_OUT, &L.outT},
-        {"fc1", &L.fc1, 0, f, d, &L.l1, 0, AWT_LORA_FC1, &L.fc1T},              {"fc2", &L.fc2, 0, d, f, &L.l2, 0, AWT_LORA_FC2, &L.fc2T}};
+        {"self_attn.q_proj", &L.qkv, 0, d, d, &L.lq, 0, AWT_LORA_Q, &L.qkvT, nullptr},   {"self_attn.k_proj", &L.qkv, d, d, d, &L.lq, 1, AWT_LORA_K, &L.qkvT, nullptr},
+        {"self_attn.v_proj", &L.qkv, 2 * d, d, d, &L.lq, 2, AWT_LORA_V, &L.qkvT, nullptr}, {"self_attn.out_proj", &L.out, 0, d, d, &L.lo_, 0, AWT_LORA_OUT, &L.outT, nullptr},
+        {"fc1", &L.fc1, 0, f, d, &L.l1, 0, AWT_LORA_FC1, &L.fc1T, &L.fc1T8},            {"fc2", &L.fc2, 0, d, f, &L.l2, 0, AWT_LORA_FC2, &L.fc2T, &L.fc2T8}};
     const float lscale = r > 0 ? c.lora_alpha / (float)r : 0.f;
     bool found = false;
     for (const Proj& p : projs) {
@@ -596,6 +613,10 @@ extern "C" int awt_encoder_set_weight(awt_encoder* e, const char* name, const fl
         } else if (!rc) rc = pack(p.lin->w, p.N, p.K, 1, p.row_off, 0);
         if (!rc && c.training)   // W^T: [K, N_total], this projection's columns start at row_off
           rc = launch_pack_weight_t(e->ctx, data, p.N, p.K, p.wT->ld, 0, p.row_off, 1.0f, p.wT->hi, p.wT->lo, s);
+        if (!rc && e->mlp_f8 && p.wT8) {   // the same W^T [K, N] in the f16f8 weight format: transposed into the scratch matrix, then packed like a forward weight
+          rc = launch_transpose_f32(e->ctx, data, p.N, p.K, e->wt_tmp, s);
+          if (!rc) rc = launch_pack_weight(e->ctx, e->wt_tmp, p.K, p.N, 1, p.wT8->ld, 0, 0, 1.0f, p.wT8->hi, p.wT8->lo, p.wT8->x8, PREC_F16F8, s);
+        }
       }
       else if (rs == key + ".bias") {
         found = true;
@@ -787,6 +808,13 @@ extern "C" int awt_op_attention(awt_ctx* c, const float* q, const float* k, cons
 }
 
 // ------------------------------------------------------------------------------------------------ LoRA fine-tune step
+extern "C" int awt_encoder_set_grad_scale_log2(awt_encoder* e, int k) {
+  AWT_REQUIRE(e && e->cfg.training, AWT_ERR_STATE, "encoder_set_grad_scale_log2: encoder was not created with cfg.training");
+  AWT_REQUIRE(k >= -60 && k <= 60, AWT_ERR_INVALID, "encoder_set_grad_scale_log2: k must be in -60 .. 60");
+  e->grad_scale_log2 = k;
+  return AWT_OK;
+}
+
 extern "C" size_t awt_encoder_train_workspace_bytes(const awt_encoder* e, int B) {
   if (!e || B <= 0 || !e->cfg.training) return 0;
   return carve_train(e, nullptr, B).bytes;
@@ -855,7 +883,11 @@ extern "C" int awt_encoder_backward_ex(awt_encoder* e, const float* d_hidden, in
   const awt_encoder_cfg& c = e->cfg;
   const int S = c.n_ctx, d = c.d_model, f = c.ffn_dim, H = c.n_heads, terms = c.mfma_terms, r = c.lora_rank;
   // products of the gradient contractions: the forward's (default), or one bf16 product per fragment pair (opt-in fast backward)
-  const int gterms = c.backward_terms ? c.backward_terms : terms;
+  // backward_terms = 5: the MLP's two backward GEMMs run in f16f8 (fp16 + two e4m3 planes, 2 MFMA-equivalents instead of 3), everything else in split-bf16
+  const bool mlp8 = e->mlp_f8;
+  const int gterms = mlp8 ? PREC_BF16X3 : (c.backward_terms ? c.backward_terms : terms);
+  // the pass carries 2^k x the gradient from the final LayerNorm on (fp16 planes: awt_encoder_set_grad_scale_log2); the adapter gradients leave unscaled
+  const float gscale = ldexpf(1.0f, e->grad_scale_log2), inv_gscale = ldexpf(1.0f, -e->grad_scale_log2);
   const int M = B * S;
   const int64_t plane = (int64_t)M * d;
   const float lscale = c.lora_alpha / (float)r;
@@ -879,10 +911,10 @@ extern "C" int awt_encoder_backward_ex(awt_encoder* e, const float* d_hidden, in
       if (!(c.lora_targets & slots[i].bit)) continue;
       float* dA = gp;
       float* dB = dA + (size_t)r * k_in;
-      int rc2 = launch_outer_reduce(e->ctx, w.du[0], w.du[1], lg.kp, i * r, r, xin[0], xin[1], k_in, 0, k_in, M, lscale, dA, k_in, 1,
+      int rc2 = launch_outer_reduce(e->ctx, w.du[0], w.du[1], lg.kp, i * r, r, xin[0], xin[1], k_in, 0, k_in, M, lscale * inv_gscale, dA, k_in, 1,
                                     w.partial, w.partial_bytes, accumulate, s);
       if (rc2) return rc2;
-      rc2 = launch_outer_reduce(e->ctx, u[0], u[1], lg.kp, i * r, r, dy0, dy1, ld_dy, slots[i].col, slots[i].n_out, M, 1.0f, dB, 1, r,
+      rc2 = launch_outer_reduce(e->ctx, u[0], u[1], lg.kp, i * r, r, dy0, dy1, ld_dy, slots[i].col, slots[i].n_out, M, inv_gscale, dB, 1, r,
                                 w.partial, w.partial_bytes, accumulate, s);
       if (rc2) return rc2;
       gp = dB + (size_t)slots[i].n_out * r;
@@ -895,7 +927,11 @@ extern "C" int awt_encoder_backward_ex(awt_encoder* e, const float* d_hidden, in
 
   // final LayerNorm
   float* dx = w.dx_a; float* dx_other = w.dx_b;
-  rc = launch_layernorm_bwd(e->ctx, d_hidden, w.x_final, e->lnf_g, nullptr, M, d, 1e-5f, dx, w.dxp[0], w.dxp[1], s); if (rc) return rc;
+  // f16f8 images of d(x_out) (the fc2 backward GEMM's operand) and of d(pre) (the fc1 backward GEMM's) live in the same bytes as their bf16 hi / lo planes
+  const Act dxp8 = make_act(w.dxp[0], w.dxp[1], (size_t)M * d, PREC_F16F8), dpre8 = make_act(w.dpre[0], w.dpre[1], (size_t)M * f, PREC_F16F8);
+  rc = mlp8 ? launch_layernorm_bwd(e->ctx, d_hidden, w.x_final, e->lnf_g, nullptr, M, d, 1e-5f, dx, nullptr, nullptr, s, gscale, &dxp8)
+            : launch_layernorm_bwd(e->ctx, d_hidden, w.x_final, e->lnf_g, nullptr, M, d, 1e-5f, dx, w.dxp[0], w.dxp[1], s, gscale);
+  if (rc) return rc;
   for (int li = c.n_layers - 1; li >= 0; --li) {
     Layer& L = e->layers[li];
     const LayerBufs& b = w.layer[li];
@@ -908,6 +944,14 @@ extern "C" int awt_encoder_backward_ex(awt_encoder* e, const float* d_hidden, in
     float* g_fc2 = g_fc1 + ((c.lora_targets & AWT_LORA_FC1) ? (size_t)r * d + (size_t)f * r : 0);
     // ---- MLP: dpre = ([dx | du2] [W2 | lscale A2]) * gelu'(pre) ; dln = [dpre | du1] [W1 | lscale A1] ; dx_mid = dx + LN2_bwd(dln)
     rc = group_backward(L.l2, w.dxp[0], w.dxp[1], d, d, fc2_slot, 1, b.ff, f, b.u2, g_fc2); if (rc) return rc;
+    if (mlp8) {   // no fc1 / fc2 adapters in this mode (encoder_create): one K segment each
+      GemmSeg s8 = seg_plain(dxp8, d, L.fc2T8, 0, d, M);
+      GemmOut o{}; set_out(o, dpre8); o.ldo = f; o.n_valid = f; o.pre_hi = b.pre[0]; o.pre_lo = b.pre[1]; o.scale = 1.0f;
+      rc = launch_gemm(e->ctx, M, f, &s8, 1, PREC_F16F8, EPI_BF16_DGELU, o, s); if (rc) return rc;
+      s8 = seg_plain(dpre8, f, L.fc1T8, 0, f, M);
+      GemmOut o2{}; o2.f32 = w.dln; o2.ldo = d; o2.n_valid = d;
+      rc = launch_gemm(e->ctx, M, d, &s8, 1, PREC_F16F8, EPI_F32, o2, s); if (rc) return rc;
+    } else {
     {
       GemmSeg sg[2];
       sg[0] = seg_plain(w.dxp[0], w.dxp[1], d, L.fc2T, 0, d, M);
@@ -922,6 +966,7 @@ extern "C" int awt_encoder_backward_ex(awt_encoder* e, const float* d_hidden, in
       if (L.l1.active) sg[1] = seg_plain(w.du[0], w.du[1], L.l1.kp, L.l1.aT, 0, L.l1.kp, M);
       GemmOut o{}; o.f32 = w.dln; o.ldo = d; o.n_valid = d;
       rc = launch_gemm(e->ctx, M, d, sg, L.l1.active ? 2 : 1, gterms, EPI_F32, o, s); if (rc) return rc;
+    }
     }
     rc = launch_layernorm_bwd(e->ctx, w.dln, b.x_mid, L.ln2_g, dx, M, d, 1e-5f, dx_other, w.dxp[0], w.dxp[1], s); if (rc) return rc;
     std::swap(dx, dx_other);   // dx = d(loss)/d(x_mid)
@@ -960,7 +1005,9 @@ extern "C" int awt_encoder_backward_ex(awt_encoder* e, const float* d_hidden, in
       GemmOut o{}; o.f32 = w.dln; o.ldo = d; o.n_valid = d;
       rc = launch_gemm(e->ctx, M, d, sg, L.lq.active ? 2 : 1, gterms, EPI_F32, o, s); if (rc) return rc;
     }
-    rc = launch_layernorm_bwd(e->ctx, w.dln, b.x_in, L.ln1_g, dx, M, d, 1e-5f, dx_other, w.dxp[0], w.dxp[1], s); if (rc) return rc;
+    rc = mlp8 ? launch_layernorm_bwd(e->ctx, w.dln, b.x_in, L.ln1_g, dx, M, d, 1e-5f, dx_other, nullptr, nullptr, s, 1.0f, &dxp8)     // feeds the layer below's fc2 backward GEMM
+              : launch_layernorm_bwd(e->ctx, w.dln, b.x_in, L.ln1_g, dx, M, d, 1e-5f, dx_other, w.dxp[0], w.dxp[1], s);
+    if (rc) return rc;
     std::swap(dx, dx_other);
   }
   if (exchange) { rc = comm_join(e->comm, s); if (rc) return rc; }

@@ -375,7 +375,8 @@ int launch_attention_bwd(awt_ctx* c, const bf16_t* q_hi, const bf16_t* q_lo, con
                          float qscale, int terms, int grad_terms, hipStream_t s);
 // dx = dres + LayerNorm_backward(dy; x, gamma)  (fp32), plus bf16 hi/lo planes of dx for the next GEMM; dres may be null
 int launch_layernorm_bwd(awt_ctx* c, const float* dy, const float* x, const float* gamma, const float* dres, int M, int d, float eps,
-                         float* dx, bf16_t* dx_hi, bf16_t* dx_lo, hipStream_t s);
+                         float* dx, bf16_t* dx_hi, bf16_t* dx_lo, hipStream_t s, float gscale = 1.0f, const Act* out8 = nullptr);   // gscale multiplies dy; out8: dx as f16f8 planes too
+int launch_transpose_f32(awt_ctx* c, const float* src, int N, int C, float* dst, hipStream_t s);   // dst [C, N] = src [N, C]^T
 // dst(row_off + c, col_off + n) = scale * src[n, c]   (transposed copy of an [N, C] fp32 matrix into fragment-major planes)
 int launch_pack_weight_t(awt_ctx* c, const float* src, int N, int C, int64_t ld, int row_off, int col_off, float scale, bf16_t* hi,
                          bf16_t* lo, hipStream_t s);

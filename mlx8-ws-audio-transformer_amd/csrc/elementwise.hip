@@ -181,9 +181,11 @@ __device__ __forceinline__ float4 ldg_once(const float4* p) {
   return *p;
 #endif
 }
+// gscale multiplies dy (the power-of-two gradient scale enters at the final LayerNorm); out8: dx also as f16f8 operand planes (the next consumer is
+// an f16f8 GEMM: awt_encoder_cfg.backward_terms = 5)
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ gamma, const float* dres, int M, int d,
-                                                            float eps, float* dx, bf16_t* dx_hi, bf16_t* dx_lo) {
+                                                            float eps, float* dx, bf16_t* dx_hi, bf16_t* dx_lo, float gscale, Act out8) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -222,7 +224,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     if (c < nchunk) {
       const float4 gy = ldg_once(dyr + c), gm = g4[c];
       v[i].x *= rstd; v[i].y *= rstd; v[i].z *= rstd; v[i].w *= rstd;        // xhat
-      g[i] = make_float4(gy.x * gm.x, gy.y * gm.y, gy.z * gm.z, gy.w * gm.w);
+      g[i] = make_float4(gy.x * gscale * gm.x, gy.y * gscale * gm.y, gy.z * gscale * gm.z, gy.w * gscale * gm.w);
       s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
       s2 += (g[i].x * v[i].x + g[i].y * v[i].y) + (g[i].z * v[i].z + g[i].w * v[i].w);
     }
@@ -248,6 +250,23 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
       reinterpret_cast<uint2*>(dx_hi + (int64_t)row * d)[c] = make_uint2(pack2(hi[0], hi[1]), pack2(hi[2], hi[3]));
       if (dx_lo) reinterpret_cast<uint2*>(dx_lo + (int64_t)row * d)[c] = make_uint2(pack2(lo[0], lo[1]), pack2(lo[2], lo[3]));
     }
+    if (out8.p16) store_act4<PREC_F16F8>(out8, (int64_t)row * d + 4 * c, y);
+  }
+}
+
+// dst [C, N] = src [N, C]^T (fp32; the f16f8 copies of W^T for the backward GEMMs are packed from it)
+__global__ __launch_bounds__(256) void transpose_f32_kernel(const float* __restrict__ src, int N, int C, float* __restrict__ dst) {
+  __shared__ float tile[32][33];
+  const int n0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  for (int r = ty; r < 32; r += 8) {
+    const int n = n0 + r, c = c0 + tx;
+    tile[r][tx] = (n < N && c < C) ? src[(int64_t)n * C + c] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int c = c0 + r, n = n0 + tx;
+    if (c < C && n < N) dst[(int64_t)c * N + n] = tile[tx][r];
   }
 }
 
@@ -473,11 +492,19 @@ int launch_im2col_conv1(awt_ctx* c, const float* mel, int B, int C, int T, int K
 }
 
 int launch_layernorm_bwd(awt_ctx* c, const float* dy, const float* x, const float* gamma, const float* dres, int M, int d, float eps,
-                         float* dx, bf16_t* dx_hi, bf16_t* dx_lo, hipStream_t s) {
+                         float* dx, bf16_t* dx_hi, bf16_t* dx_lo, hipStream_t s, float gscale, const Act* out8) {
   AWT_REQUIRE(dy && x && gamma && dx, AWT_ERR_INVALID, "layernorm_bwd: null argument");
   AWT_REQUIRE(M > 0 && d > 0 && d % 4 == 0 && d <= 64 * 4 * kLnMaxChunks, AWT_ERR_INVALID, "layernorm_bwd: d must be a multiple of 4 and <= 1280");
+  AWT_REQUIRE(!out8 || (out8->p16 && out8->hi8 && out8->lo8), AWT_ERR_INVALID, "layernorm_bwd: the f16f8 output needs all three planes");
   ProfScope prof(c, AWT_PROF_LAYERNORM, s, 0.0);
-  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, s, dy, x, gamma, dres, M, d, eps, dx, dx_hi, dx_lo);
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, s, dy, x, gamma, dres, M, d, eps, dx, dx_hi, dx_lo, gscale, out8 ? *out8 : Act{});
+  AWT_HIP_CHECK(hipGetLastError());
+  return AWT_OK;
+}
+
+int launch_transpose_f32(awt_ctx* c, const float* src, int N, int C, float* dst, hipStream_t s) {
+  AWT_REQUIRE(src && dst && N > 0 && C > 0, AWT_ERR_INVALID, "transpose_f32: bad argument");
+  hipLaunchKernelGGL(transpose_f32_kernel, dim3((N + 31) / 32, (C + 31) / 32), dim3(256), 0, s, src, N, C, dst);
   AWT_HIP_CHECK(hipGetLastError());
   return AWT_OK;
 }

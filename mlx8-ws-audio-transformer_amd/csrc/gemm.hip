@@ -254,7 +254,7 @@ __device__ __forceinline__ void store_out4(const GemmOut& o, int m, int n, float
 // b0 / b1: the lane's eight bias values, loaded once per tile (its columns are the same in every strip).
 template <int EPI, bool FULL>
 __device__ __forceinline__ void store_out8_f8(const GemmOut& o, int m, int n, float4 acc0, float4 acc1, float4 side0, float4 side1, float4 b0, float4 b1, int M) {
-  static_assert(EPI != EPI_BF16_GELU_SAVE && EPI != EPI_BF16_DGELU, "training epilogues have no f16f8 form");
+  static_assert(EPI != EPI_BF16_GELU_SAVE, "the forward training epilogue has no f16f8 form");   // EPI_BF16_DGELU: the MLP's backward GEMM (backward_terms = 5)
   if constexpr (!FULL) { if (m >= M || n >= o.n_valid) return; }
   float v[8] = {acc0.x, acc0.y, acc0.z, acc0.w, acc1.x, acc1.y, acc1.z, acc1.w};
   const float sd[8] = {side0.x, side0.y, side0.z, side0.w, side1.x, side1.y, side1.z, side1.w};
@@ -286,8 +286,16 @@ __device__ __forceinline__ void store_out8_f8(const GemmOut& o, int m, int n, fl
     off = (int64_t)which * o.plane_stride + (((int64_t)b * o.H + h) * o.S + s) * 64 + e;
   } else {
     off = (int64_t)m * o.ldo + n;
+    if constexpr (EPI == EPI_BF16_DGELU) {
 #pragma unroll
-    for (int t = 0; t < 8; ++t) v[t] = EPI == EPI_BF16_GELU ? gelu_erf(v[t]) : v[t] * o.scale;
+      for (int t = 0; t < 8; ++t) {
+        const float x = sd[t];   // d/dx gelu(x) = Phi(x) + x phi(x), x = the saved pre-activation (load_side4)
+        v[t] *= 0.5f * (1.0f + erf_fast(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) v[t] = EPI == EPI_BF16_GELU ? gelu_erf(v[t]) : v[t] * o.scale;
+    }
   }
   const float invl8 = inv8 * pow2f(-kF8Lo), liml8 = lim8 * pow2f(-kF8Lo);
   bf16_t h[8]; float l[8];
@@ -833,7 +841,7 @@ __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, CFG::WM * CFG::WN == 4 ? 2 
   const int em0 = m0 + wr * TM * 32, en = n0 + wc * 64 + c8;
   float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
   if (g.out.bias && en < g.out.n_valid) { b0 = *reinterpret_cast<const float4*>(g.out.bias + en); b1 = *reinterpret_cast<const float4*>(g.out.bias + en + 4); }
-  constexpr bool SIDE = EPI == EPI_F32_RESID || EPI == EPI_F32_GELU_POS;
+  constexpr bool SIDE = EPI == EPI_F32_RESID || EPI == EPI_F32_GELU_POS || EPI == EPI_BF16_DGELU;
   auto strips = [&](auto full_t) {
     constexpr bool FULL = decltype(full_t)::value;
     float4 side[4][2], side_next[4][2];
@@ -1195,7 +1203,7 @@ int launch_epi(GemmArgs a, int prec, hipStream_t s) {
 #endif
   }
   if (prec == PREC_F16F8) {
-    if constexpr (EPI == EPI_BF16_GELU_SAVE || EPI == EPI_BF16_DGELU) return awt_fail(AWT_ERR_INVALID, "gemm: the training epilogues have no f16f8 form");
+    if constexpr (EPI == EPI_BF16_GELU_SAVE) return awt_fail(AWT_ERR_INVALID, "gemm: the forward training epilogue has no f16f8 form");
     else {
       const int64_t t256f = (int64_t)((a.M + 127) / 128) * (a.N / 256);
       int tile = g_force_tile;

@@ -15,6 +15,7 @@ them to the library when they change.
 from __future__ import annotations
 
 import ctypes as C
+import math
 from dataclasses import dataclass
 from types import SimpleNamespace
 from typing import Dict, Optional
@@ -68,6 +69,12 @@ class _EncoderLoRAFunction(torch.autograd.Function):
         enc, L = ctx.enc, _lib.lib()
         d_out = d_out.to(torch.float32).contiguous()
         n = L.awt_encoder_lora_grad_count(enc._handle)
+        if enc.backward_precision == "f16f8":
+            # fp16 planes want gradients of order one: the pass carries 2^k x the gradient (largest |d loss / d hidden| -> ~2^6) and the library divides
+            # the adapter gradients by 2^k on the way out.  One scalar read-back per step; a zero or non-finite gradient keeps k = 0.
+            amax = float(d_out.abs().max())
+            k = 0 if not (amax > 0.0 and math.isfinite(amax)) else max(-60, min(60, 6 - math.frexp(amax)[1]))
+            _lib.check(L.awt_encoder_set_grad_scale_log2(enc._handle, k))
         if enc._grad_flat is not None:
             # bound gradient buffer (bind_grad_buffer): the library writes / accumulates the adapter gradients straight into
             # the flat buffer the parameters' .grad tensors are views of, and -- when asked -- averages them over the ranks
@@ -141,8 +148,10 @@ class NativeWhisperEncoder(nn.Module):
         self._auto_precision = precision is None and not trainable
         if precision is None:
             precision = "bf16x3" if trainable else DEFAULT_PRECISION
-        if backward_precision not in (None, precision, "bf16"):
-            raise ValueError("backward_precision must be None (= precision) or 'bf16'")
+        if backward_precision not in (None, precision, "bf16", "f16f8"):
+            raise ValueError("backward_precision must be None (= precision), 'bf16' or 'f16f8' (the MLP's backward GEMMs in the f16f8 operand format)")
+        if backward_precision == "f16f8" and (precision != "bf16x3" or not trainable or (lora is not None and {"fc1", "fc2"} & set(lora.targets))):
+            raise ValueError("backward_precision='f16f8' needs trainable=True, precision='bf16x3' and no adapters on fc1 / fc2")
         self.backward_precision = backward_precision
         if precision not in PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(PRECISIONS)}")

@@ -155,3 +155,45 @@ def test_lora_gradients_at_large_width():
             ref = ref_g[name]
             err = float(np.abs(p.grad.cpu().numpy() - ref).max()) / max(float(np.abs(ref).max()), 1e-12)
             assert err < 1e-3, (name, err)
+
+
+@pytest.mark.parametrize("name,trimmed,targets,r,gmag", [("mini", True, ("q_proj", "v_proj"), 8, 1.0), ("tiny", True, ("q_proj", "k_proj", "v_proj", "out_proj"), 16, 1e-6),
+                                                         ("small", False, ("q_proj", "v_proj"), 8, 1e-3)])
+def test_f16f8_mlp_backward_matches_oracle_autograd(name, trimmed, targets, r, gmag):
+    """awt_encoder_cfg.backward_terms = 5 (`backward_precision="f16f8"`): the MLP's two backward GEMMs in the f16f8 operand format with a power-of-two
+    gradient scale chosen from max |d loss / d hidden| (here tiny and large upstream gradients on purpose).  Same bound against the oracle's autograd as
+    the split-bf16 backward, and close to it."""
+    from mlx8_ws_audio_transformer_amd.encoder import NativeWhisperEncoder
+    cfg = wts.config(name, trimmed)
+    spec = wts.LoraSpec(r=r, alpha=16.0, targets=targets)
+    W = wts.init_encoder_weights(cfg, 0, "test")
+    LW = wts.init_lora_weights(cfg, spec, 0, zero_b=False)
+    B = 2
+    mel = oracle_mel.whisper_logmel(piano_clips_f32(B), n_samples=cfg.n_frames * 160)
+    dout = (gmag * wts.unit_variates("dout", B * cfg.max_source_positions * cfg.d_model, 3).reshape(B, cfg.max_source_positions, cfg.d_model)
+            / np.sqrt(cfg.max_source_positions)).astype(np.float32)
+    _, ref_g = _oracle_grads(W, LW, mel, cfg, spec, dout)
+    got = {}
+    for bp in (None, "f16f8"):
+        enc = NativeWhisperEncoder(cfg, precision="bf16x3", lora=spec, trainable=True, seed=0, init_profile="test", backward_precision=bp)
+        enc.load_state_dict({k: torch.from_numpy(v) for k, v in {**W, **LW}.items()})
+        out = enc(torch.from_numpy(mel).cuda()).last_hidden_state
+        (out * torch.from_numpy(dout).cuda()).sum().backward()
+        got[bp] = {n: p.grad.cpu().numpy() for n, p in enc.named_parameters() if "lora_" in n}
+    worst = worst_vs_bf16 = 0.0
+    for k, g_ref in ref_g.items():
+        scale = max(np.abs(g_ref).max(), 1e-30)
+        worst = max(worst, np.abs(got["f16f8"][k] - g_ref).max() / scale)
+        worst_vs_bf16 = max(worst_vs_bf16, np.abs(got["f16f8"][k] - got[None][k]).max() / scale)
+    print("worst relative gradient error f16f8-MLP backward:", worst, " vs split-bf16 backward:", worst_vs_bf16)
+    assert worst < 2e-3 and worst_vs_bf16 < 5e-4, (worst, worst_vs_bf16)
+    assert worst_vs_bf16 > 0.0                              # the f16f8 GEMMs really ran
+
+
+def test_f16f8_mlp_backward_rejects_unsupported_configurations():
+    from mlx8_ws_audio_transformer_amd.encoder import NativeWhisperEncoder
+    cfg = wts.config("mini", True)
+    with pytest.raises(ValueError):                          # adapters on the MLP are not part of this mode
+        NativeWhisperEncoder(cfg, precision="bf16x3", lora=wts.LoraSpec(r=8, alpha=16.0, targets=("q_proj", "fc1")), trainable=True, backward_precision="f16f8")
+    with pytest.raises(ValueError):                          # inference encoders have no backward
+        NativeWhisperEncoder(cfg, precision="bf16x3", lora=wts.LoraSpec(r=8, alpha=16.0, targets=("q_proj",)), backward_precision="f16f8")
