@@ -682,10 +682,22 @@ __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, CFG::WM * CFG::WN == 4 ? 2 
 
   // ---- prologue: K-tile 0 into stage 0 and into the W registers
   open_segment(0);
+#ifdef AWT_DIAG_NO_PROLOGUE   // timing-only (wrong results): K-tile 0's operands are "already there" -- the upper bound of what a persistent workgroup
+  // that prefetches the next tile's first K-tile during its epilogue could hide (profiles/r03_gemm_experiments.txt)
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) w16[ks][j] = (bf16x8){};
+#pragma unroll
+  for (int j = 0; j < TN; ++j) { w8[j][0] = w8[j][1] = (bf16x8){}; if constexpr (!WX) { wl8[j][0] = wl8[j][1] = (bf16x8){}; } }
+  // stage 0 zeroed (uninitialised LDS would put NaNs into the outputs, and NaN data changes the power / clock of every later kernel)
+  for (int o = tid * 16; o < STAGE; o += NT * 16) *reinterpret_cast<uint4*>(smem + o) = make_uint4(0u, 0u, 0u, 0u);
+#else
   [&]<int... O>(std::integer_sequence<int, O...>) { (dma(std::integral_constant<int, O>{}, smem), ...); }(std::make_integer_sequence<int, NDMA>{});
   [&]<int... S>(std::integer_sequence<int, S...>) { (load_w16(std::integral_constant<int, S>{}), ...); }(std::make_integer_sequence<int, 4>{});
   load_w8();
   wait_vm<0>();
+#endif
   __builtin_amdgcn_s_barrier();
 #ifdef AWT_DIAG_NO_WLOAD
   diag_w_loaded = true;
