@@ -319,7 +319,7 @@ def test_decoder_adapters_forward_and_gradients_match_torch_autograd(targets, cr
     out_r = ref(input_features=mel, labels=labels)
     out_r.loss.backward()
     assert abs(float(out_n.loss.detach()) - float(out_r.loss.detach())) < 2e-4 * abs(float(out_r.loss.detach()))
-    assert float((out_n.logits.float() - out_r.logits.float()).abs().max()) < 2e-3
+    assert float((out_n.logits.detach().float() - out_r.logits.detach().float()).abs().max()) < 2e-3
     # the adapters really act: the loss differs from the adapter-free reference value
     assert abs(float(out_n.loss.detach()) - float(G["loss"])) > 1e-4
     ge_n = torch.cat([p.grad.flatten() for n, p in nat.encoder.named_parameters() if "lora_" in n])
