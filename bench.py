@@ -77,8 +77,10 @@ def parse():
     ap.add_argument("--lora-r", type=int, default=8)
     ap.add_argument("--decoder-dtype", default="fp32", choices=["fp32", "bf16"], help="finetune workload with --torch-decoder: dtype of the stock-PyTorch decoder")
     ap.add_argument("--torch-decoder", action="store_true", help="finetune workload: stock-PyTorch decoder + CE instead of the native ones (A/B)")
-    ap.add_argument("--backward-precision", default=None, choices=["bf16", "f16f8"],
-                    help="finetune workload: gradient contractions in single bf16 products (opt-in; default = the forward's precision)")
+    ap.add_argument("--backward-precision", default=None, choices=["bf16", "f16f8", "bf16x3"],
+                    help="finetune workload.  Default f16f8: the MLP of the step (fc1 / fc2 forward and their two backward GEMMs) in the f16f8 operand format, "
+                         "everything else in the forward's split-bf16 (same gradient error against the oracle's autograd, DESIGN.md 4.5); bf16x3: split-bf16 "
+                         "everywhere (the library's own default); bf16: gradient contractions in single bf16 products (~0.5 %% gradient error)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL, the real multi-GPU path) or gloo (rehearsal of the N > 1 code path on one GPU: every rank on cuda:0)")
     return ap.parse_args()
@@ -331,9 +333,12 @@ def finetune_main(a):
     cfg = wts.config(a.model, a.trimmed)
     B = a.batch
     pcm = torch.from_numpy(synth.synth_clips_i16(B, seed=1234, first=rank * B)).to(dev)
+    bwd = a.backward_precision or ("f16f8" if a.precision == "bf16x3" else None)
+    if bwd == "bf16x3":
+        bwd = None
     model = WhisperLoRAModel(cfg, wts.LoraSpec(r=a.lora_r, alpha=16.0), precision=a.precision, device=str(dev),
                              decoder_autocast=torch.bfloat16 if (a.decoder_dtype == "bf16" and a.torch_decoder) else None,
-                             backward_precision=a.backward_precision, native_decoder=not a.torch_decoder)
+                             backward_precision=bwd, native_decoder=not a.torch_decoder)
     g = torch.Generator().manual_seed(rank)
     labels = torch.randint(0, 51864, (B, 12), generator=g); labels[:, 0] = 50258
     args = Seq2SeqTrainingArguments(per_device_train_batch_size=B, learning_rate=1e-5, max_steps=10 ** 6, predict_with_generate=False)
@@ -375,7 +380,9 @@ def finetune_main(a):
             "config": {"workload": "LoRA r=%d (q_proj, v_proj) fine-tune step: log-mel + encoder fwd/bwd (HIP) + decoder/CE (%s) + gradient exchange + AdamW" % (
                            a.lora_r, "torch" if a.torch_decoder else "HIP"),
                        "clips_per_gpu_per_step": B, "global_batch": B * world, "precision": a.precision, "label_tokens": 12, "decoder_dtype": a.decoder_dtype,
-                       "backward_precision": a.backward_precision or a.precision,
+                       "backward_precision": bwd or a.precision,
+                       "mlp_operand_format": ("f16f8: fc1 / fc2 forward and their two backward GEMMs on the fp16 + 2 x e4m3 operand format (2 MFMA-equivalents, 2^-16 per "
+                                              "operand), gradients carried x 2^k (k from max |d loss / d hidden| each step)" if bwd == "f16f8" else "as the rest of the step"),
                        "decoder_cross_attention": ("torch" if a.torch_decoder else
                                                    "absorbed (q_h W_k,h against the encoder states, batched GEMMs; native_decoder._AbsorbedCross)"
                                                    if getattr(model.decoder, "absorbed_cross", lambda *_: False)(12, cfg.max_source_positions)
@@ -383,7 +390,8 @@ def finetune_main(a):
                        "weights": "seed-0 random init, arbitrary fp32 values (SURVEY.md 8(d) C3); adapters A ~ N(0, 1/d), B = 0",
                        "adapter_grad_elems": tr.bucket.numel, "gradient_exchange": tr.exchange,
                        "parallelism": "dp%d, one in-place mean all-reduce of %.2f MB per step" % (world, tr.bucket.numel * 4 / 1e6)},
-            "roofline": {"bound": "mfma", "kernel": "gemm_kernel<%s> (every GEMM of the step: encoder forward and backward, adapter terms, decoder)" % a.precision,
+            "roofline": {"bound": "mfma", "kernel": "gemm_kernel<%s>%s (every GEMM of the step: encoder forward and backward, adapter terms, decoder)" % (
+                             a.precision, " + gemm_f8_kernel (the MLP's four GEMMs per layer)" if bwd == "f16f8" else ""),
                          "achieved": round(achieved, 2), "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_DENSE_TFLOPS, 4),
                          "traffic": None, "launches": gemm_n, "avg_launch_ms": round(gemm_ms / max(gemm_n, 1), 4),
                          "mfma_issue_frac": round(terms * achieved / PEAK_BF16_DENSE_TFLOPS, 4),

@@ -124,10 +124,11 @@ typedef struct awt_encoder_cfg {
   int32_t backward_terms;   /* products of the backward pass' gradient contractions: 0 = mfma_terms (default: gradients
                                to 3e-5 of fp32 autograd), 1 with mfma_terms = 3 = one bf16 product (the usual
                                mixed-precision trade: ~0.5 % gradient error, 1.4x faster step); the attention scores are
-                               recomputed in split-bf16 either way.  5 with mfma_terms = 3: the MLP's two backward GEMMs
-                               (d pre = (dx W2) gelu'(pre), d ln2 = d pre W1) run in the f16f8 operand format (2 instead of 3
-                               MFMA-equivalents, 2^-16 per operand like split-bf16), everything else in split-bf16; fp16 planes
-                               want gradients of order one: see awt_encoder_set_grad_scale_log2.  No fc1 / fc2 adapters.   */
+                               recomputed in split-bf16 either way.  5 with mfma_terms = 3: the MLP of the training step -- fc1 / fc2
+                               forward and their two backward GEMMs (d pre = (dx W2) gelu'(pre), d ln2 = d pre W1) -- runs in the
+                               f16f8 operand format (2 instead of 3 MFMA-equivalents, 2^-16 per operand like split-bf16), everything
+                               else in split-bf16; fp16 planes want gradients of order one: see awt_encoder_set_grad_scale_log2.
+                               No fc1 / fc2 adapters.                                                                       */
 } awt_encoder_cfg;
 
 enum { AWT_LORA_Q = 1, AWT_LORA_K = 2, AWT_LORA_V = 4, AWT_LORA_OUT = 8, AWT_LORA_FC1 = 16, AWT_LORA_FC2 = 32 };

@@ -178,6 +178,7 @@ struct Layer {
   Linear qkv, out, fc1, fc2;
   Planes qkvT, outT, fc1T, fc2T;   // training: transposed copies [K, N] of the frozen weights (dX = dY W)
   Planes fc1T8, fc2T8;             // backward_terms = 5: the MLP's transposed copies in the f16f8 weight format (the MLP's two backward GEMMs run in it)
+  Planes fc1_8, fc2_8;             // ... and its forward weights in the same format (the training forward's fc1 / fc2 run in it too)
   float *ln1_g = nullptr, *ln1_b = nullptr, *ln2_g = nullptr, *ln2_b = nullptr;
   LoraGroup lq, lo_, l1, l2;
 };
@@ -441,6 +442,16 @@ int encoder_layer(awt_encoder* e, Layer& L, const LayerBufs& b, int Bc, bool sav
     GemmOut o{}; o.f32 = b.x_mid; o.resid = b.x_in; o.ldo = d;
     rc = linear_with_lora(e, b.uo, b.att, d, L.out, L.lo_, M, EPI_F32_RESID, o, s); if (rc) return rc;
   }
+  if (save && e->mlp_f8) {   // backward_terms = 5: the MLP of the training step in the f16f8 operand format (no fc1 / fc2 adapters in this mode)
+    const Act aln2 = make_act(b.ln2[0], b.ln2[1], (size_t)plane, PREC_F16F8), aff = make_act(b.ff[0], b.ff[1], (size_t)M * f, PREC_F16F8);
+    rc = launch_layernorm(e->ctx, b.x_mid, L.ln2_g, L.ln2_b, M, d, 1e-5f, nullptr, aln2, PREC_F16F8, s); if (rc) return rc;
+    GemmSeg s1 = seg_plain(aln2, d, L.fc1_8, 0, d, M);
+    GemmOut o1{}; set_out(o1, aff); o1.ldo = f; o1.n_valid = f; o1.bias = L.fc1.bias; o1.hi2 = b.pre[0]; o1.lo2 = b.pre[1]; o1.scale = 1.0f;
+    rc = launch_gemm(e->ctx, M, f, &s1, 1, PREC_F16F8, EPI_BF16_GELU_SAVE, o1, s); if (rc) return rc;
+    GemmSeg s2 = seg_plain(aff, f, L.fc2_8, 0, f, M);
+    GemmOut o2{}; o2.f32 = b.x_out; o2.resid = b.x_mid; o2.ldo = d; o2.n_valid = d; o2.bias = L.fc2.bias;
+    return launch_gemm(e->ctx, M, d, &s2, 1, PREC_F16F8, EPI_F32_RESID, o2, s);
+  }
   rc = launch_layernorm(e->ctx, b.x_mid, L.ln2_g, L.ln2_b, M, d, 1e-5f, nullptr, feeds(make_act(b.ln2[0], b.ln2[1], (size_t)plane, terms), L.fc1, L.l1), terms, s); if (rc) return rc;
   {
     GemmOut o{}; set_out(o, feeds(make_act(b.ff[0], b.ff[1], (size_t)M * f, terms), L.fc2, L.l2)); o.ldo = f; o.hi2 = b.pre[0]; o.lo2 = b.pre[1];
@@ -546,6 +557,8 @@ extern "C" int awt_encoder_create(awt_ctx* c, const awt_encoder_cfg* cfg, awt_en
       if (!rc) rc = alloc_planes(e, &L.fc2T, f, d);
       if (!rc && e->mlp_f8) rc = alloc_planes_f8(e, &L.fc1T8, d, f);
       if (!rc && e->mlp_f8) rc = alloc_planes_f8(e, &L.fc2T8, f, d);
+      if (!rc && e->mlp_f8) rc = alloc_planes_f8(e, &L.fc1_8, f, d);
+      if (!rc && e->mlp_f8) rc = alloc_planes_f8(e, &L.fc2_8, d, f);
     }
     float** lnp[4] = {&L.ln1_g, &L.ln1_b, &L.ln2_g, &L.ln2_b};
     for (int k = 0; k < 4 && !rc; ++k) rc = dev_alloc(e, (void**)lnp[k], (size_t)d * 4);
@@ -589,11 +602,11 @@ extern "C" int awt_encoder_set_weight(awt_encoder* e, const char* name, const fl
       return awt_fail(AWT_ERR_INVALID, std::string("set_weight: unknown parameter ") + name);
     Layer& L = e->layers[li];
     std::string rs(rest);
-    struct Proj { const char* key; Linear* lin; int row_off; int N; int K; LoraGroup* lg; int slot; uint32_t bit; Planes* wT; Planes* wT8; };
+    struct Proj { const char* key; Linear* lin; int row_off; int N; int K; LoraGroup* lg; int slot; uint32_t bit; Planes* wT; Planes* wT8; Planes* w8; };
     Proj projs[] = {
-        {"self_attn.q_proj", &L.qkv, 0, d, d, &L.lq, 0, AWT_LORA_Q, &L.qkvT, nullptr},   {"self_attn.k_proj", &L.qkv, d, d, d, &L.lq, 1, AWT_LORA_K, &L.qkvT, nullptr},
-        {"self_attn.v_proj", &L.qkv, 2 * d, d, d, &L.lq, 2, AWT_LORA_V, &L.qkvT, nullptr}, {"self_attn.out_proj", &L.out, 0, d, d, &L.lo_, 0, AWT_LORA_OUT, &L.outT, nullptr},
-        {"fc1", &L.fc1, 0, f, d, &L.l1, 0, AWT_LORA_FC1, &L.fc1T, &L.fc1T8},            {"fc2", &L.fc2, 0, d, f, &L.l2, 0, AWT_LORA_FC2, &L.fc2T, &L.fc2T8}};
+        {"self_attn.q_proj", &L.qkv, 0, d, d, &L.lq, 0, AWT_LORA_Q, &L.qkvT, nullptr, nullptr},   {"self_attn.k_proj", &L.qkv, d, d, d, &L.lq, 1, AWT_LORA_K, &L.qkvT, nullptr, nullptr},
+        {"self_attn.v_proj", &L.qkv, 2 * d, d, d, &L.lq, 2, AWT_LORA_V, &L.qkvT, nullptr, nullptr}, {"self_attn.out_proj", &L.out, 0, d, d, &L.lo_, 0, AWT_LORA_OUT, &L.outT, nullptr, nullptr},
+        {"fc1", &L.fc1, 0, f, d, &L.l1, 0, AWT_LORA_FC1, &L.fc1T, &L.fc1T8, &L.fc1_8},            {"fc2", &L.fc2, 0, d, f, &L.l2, 0, AWT_LORA_FC2, &L.fc2T, &L.fc2T8, &L.fc2_8}};
     const float lscale = r > 0 ? c.lora_alpha / (float)r : 0.f;
     bool found = false;
     for (const Proj& p : projs) {
@@ -616,6 +629,7 @@ extern "C" int awt_encoder_set_weight(awt_encoder* e, const char* name, const fl
         if (!rc && e->mlp_f8 && p.wT8) {   // the same W^T [K, N] in the f16f8 weight format: transposed into the scratch matrix, then packed like a forward weight
           rc = launch_transpose_f32(e->ctx, data, p.N, p.K, e->wt_tmp, s);
           if (!rc) rc = launch_pack_weight(e->ctx, e->wt_tmp, p.K, p.N, 1, p.wT8->ld, 0, 0, 1.0f, p.wT8->hi, p.wT8->lo, p.wT8->x8, PREC_F16F8, s);
+          if (!rc) rc = launch_pack_weight(e->ctx, data, p.N, p.K, 1, p.w8->ld, 0, 0, 1.0f, p.w8->hi, p.w8->lo, p.w8->x8, PREC_F16F8, s);
         }
       }
       else if (rs == key + ".bias") {

@@ -254,7 +254,7 @@ __device__ __forceinline__ void store_out4(const GemmOut& o, int m, int n, float
 // b0 / b1: the lane's eight bias values, loaded once per tile (its columns are the same in every strip).
 template <int EPI, bool FULL>
 __device__ __forceinline__ void store_out8_f8(const GemmOut& o, int m, int n, float4 acc0, float4 acc1, float4 side0, float4 side1, float4 b0, float4 b1, int M) {
-  static_assert(EPI != EPI_BF16_GELU_SAVE, "the forward training epilogue has no f16f8 form");   // EPI_BF16_DGELU: the MLP's backward GEMM (backward_terms = 5)
+  // EPI_BF16_GELU_SAVE / EPI_BF16_DGELU: the MLP's forward / backward GEMMs of the training step with backward_terms = 5
   if constexpr (!FULL) { if (m >= M || n >= o.n_valid) return; }
   float v[8] = {acc0.x, acc0.y, acc0.z, acc0.w, acc1.x, acc1.y, acc1.z, acc1.w};
   const float sd[8] = {side0.x, side0.y, side0.z, side0.w, side1.x, side1.y, side1.z, side1.w};
@@ -286,7 +286,15 @@ __device__ __forceinline__ void store_out8_f8(const GemmOut& o, int m, int n, fl
     off = (int64_t)which * o.plane_stride + (((int64_t)b * o.H + h) * o.S + s) * 64 + e;
   } else {
     off = (int64_t)m * o.ldo + n;
-    if constexpr (EPI == EPI_BF16_DGELU) {
+    if constexpr (EPI == EPI_BF16_GELU_SAVE) {   // the pre-activation as a bf16 hi / lo pair (what EPI_BF16_DGELU reads back), then the f16f8 planes of gelu(pre)
+      bf16_t ph[8], pl[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) split_bf16(v[t], ph[t], pl[t]);
+      *reinterpret_cast<uint4*>(o.hi2 + off) = make_uint4(pack2(ph[0], ph[1]), pack2(ph[2], ph[3]), pack2(ph[4], ph[5]), pack2(ph[6], ph[7]));
+      if (o.lo2) *reinterpret_cast<uint4*>(o.lo2 + off) = make_uint4(pack2(pl[0], pl[1]), pack2(pl[2], pl[3]), pack2(pl[4], pl[5]), pack2(pl[6], pl[7]));
+#pragma unroll
+      for (int t = 0; t < 8; ++t) v[t] = gelu_erf(v[t]);
+    } else if constexpr (EPI == EPI_BF16_DGELU) {
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
         const float x = sd[t];   // d/dx gelu(x) = Phi(x) + x phi(x), x = the saved pre-activation (load_side4)
@@ -1215,8 +1223,7 @@ int launch_epi(GemmArgs a, int prec, hipStream_t s) {
 #endif
   }
   if (prec == PREC_F16F8) {
-    if constexpr (EPI == EPI_BF16_GELU_SAVE) return awt_fail(AWT_ERR_INVALID, "gemm: the forward training epilogue has no f16f8 form");
-    else {
+    {
       const int64_t t256f = (int64_t)((a.M + 127) / 128) * (a.N / 256);
       int tile = g_force_tile;
       if (!tile) tile = (a.N % 256 == 0 && t256f >= kSlots) ? 256 : 128;
