@@ -360,3 +360,30 @@ def test_trainer_steps_encoder_and_decoder_adapters_together(tmp_path):
     tr.save_model(full=True)
     sd = torch.load(tmp_path / "lora_adapters.pt")["lora"]
     assert any(k.startswith("decoder.") for k in sd) and (tmp_path / "model.safetensors").exists()
+
+
+def test_absorbed_cross_attention_equals_projected_form_at_whisper_small_shape():
+    """The training step's cross-attention at the reference's real shape -- d = 768, 12 heads, S = 1500 encoder positions, L = 12 label rows (H L = 144) --
+    in its absorbed form against the projected key / value form: loss, logits and d(loss) / d(encoder states)."""
+    from mlx8_ws_audio_transformer_amd.native_decoder import NativeWhisperDecoder
+    d, H, S, B, L, vocab = 768, 12, 1500, 3, 12, 1024
+    Wd = wts.init_decoder_weights(d, 2, 3072, vocab, 64, seed=0)
+    enc0 = _rand((B, S, d), 7)
+    g = torch.Generator().manual_seed(3)
+    ids = torch.randint(3, vocab, (B, L), generator=g).cuda()
+    labels = torch.randint(3, vocab, (B, L), generator=g).cuda()
+    labels[0, -2:] = -100
+    res = {}
+    for mode in ("kv", "absorbed"):
+        dec = NativeWhisperDecoder(d, 2, H, 3072, vocab, 64).cuda()
+        dec.load_state_dict({k: torch.from_numpy(v) for k, v in Wd.items()})
+        dec.cross_mode = mode
+        enc = enc0.clone().requires_grad_(True)
+        loss, logits = dec.loss(ids, labels, enc)
+        loss.backward()
+        res[mode] = (float(loss.detach()), logits.detach().float(), enc.grad.clone())
+    assert abs(res["kv"][0] - res["absorbed"][0]) < 2e-5 * abs(res["kv"][0])
+    assert float((res["kv"][1] - res["absorbed"][1]).abs().max()) < 2e-4
+    gk, ga = res["kv"][2], res["absorbed"][2]
+    assert float(gk.abs().max()) > 0
+    assert float((gk - ga).abs().max()) < 2e-4 * float(gk.abs().max())
