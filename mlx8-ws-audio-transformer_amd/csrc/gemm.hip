@@ -536,6 +536,21 @@ __device__ __forceinline__ bf16x8 lds_read16(unsigned addr) {
 }
 template <int N> __device__ __forceinline__ void lgkm_wait(bf16x8& f) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(N)); }
 template <int N> __device__ __forceinline__ void lgkm_wait(bf16x8& f0, bf16x8& f1) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f0), "+v"(f1) : "n"(N)); }
+#ifdef AWT_DIAG_MFMA16   // timing-only (wrong results, finite): every 32x32 MFMA is issued as the two 16x16 MFMAs of the same matrix-pipe cycles and operand registers
+// (v_mfma_f32_16x16x32_f16 for 32x32x16_f16, v_mfma_scale_f32_16x16x128_f8f6f4 for 32x32x64), each 16x16 sub-accumulator of a 32x32 block getting
+// what the real variant would give it: what VERDICT r2 item 1(c)'s kernel would issue, without its fragment layouts (profiles/r03_gemm_experiments.txt)
+__device__ __forceinline__ void diag_mfma16_f16(f32x16& acc, bf16x8 a, bf16x8 b, int ks) {
+  f32x4* s = reinterpret_cast<f32x4*>(&acc);
+  s[(2 * ks) & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), s[(2 * ks) & 3], 0, 0, 0);
+  s[(2 * ks + 1) & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), s[(2 * ks + 1) & 3], 0, 0, 0);
+}
+template <int SA, int SB>
+__device__ __forceinline__ void diag_mfma16_f8(f32x16& acc, i32x8 a, i32x8 b, int which) {
+  f32x4* s = reinterpret_cast<f32x4*>(&acc);
+  s[2 * which] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, s[2 * which], 0, 0, 0, SA, 0, SB);
+  s[2 * which + 1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, s[2 * which + 1], 0, 0, 0, SA, 0, SB);
+}
+#endif
 __device__ __forceinline__ i32x8 cat8(bf16x8 lo, bf16x8 hi) {
   return __builtin_shufflevector(__builtin_bit_cast(i32x4_t, lo), __builtin_bit_cast(i32x4_t, hi), 0, 1, 2, 3, 4, 5, 6, 7);
 }
@@ -777,7 +792,11 @@ __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, CFG::WM * CFG::WN == 4 ? 2 
 #endif
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
+#ifdef AWT_DIAG_MFMA16
+        for (int j = 0; j < TN; ++j) diag_mfma16_f16(acc[i][j], af[S % (AD + 1)], w16[ks][j], ks);
+#else
         for (int j = 0; j < TN; ++j) acc[i][j] = mfma32<true>(af[S % (AD + 1)], w16[ks][j], acc[i][j]);
+#endif
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (PF && i == TM - 1) load_w16(std::integral_constant<int, ks>{});     // ring: this k-step's registers, for K-tile kt + 1
       }(), ...);
@@ -792,7 +811,11 @@ __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, CFG::WM * CFG::WN == 4 ? 2 
           __builtin_amdgcn_sched_barrier(0);
           const i32x8 a8 = cat8(ax[0], ax[1]);
 #pragma unroll
+#ifdef AWT_DIAG_MFMA16
+          for (int j = 0; j < TN; ++j) diag_mfma16_f8<e8m0(-kF8Act), e8m0(-kF8Wgt - kF8Lo)>(acc[I][j], a8, cat8(wl8[j][0], wl8[j][1]), 0);
+#else
           for (int j = 0; j < TN; ++j) acc[I][j] = mfma32_f8<e8m0(-kF8Act), e8m0(-kF8Wgt - kF8Lo)>(a8, cat8(wl8[j][0], wl8[j][1]), acc[I][j]);
+#endif
           __builtin_amdgcn_sched_barrier(0);
           if constexpr (I + 1 < TM) read_x(std::integral_constant<int, I + 1>{});
         }
@@ -803,14 +826,22 @@ __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, CFG::WM * CFG::WN == 4 ? 2 
           __builtin_amdgcn_sched_barrier(0);
           const i32x8 al8 = cat8(yb[0], yb[1]);
 #pragma unroll
+#ifdef AWT_DIAG_MFMA16
+          for (int j = 0; j < TN; ++j) diag_mfma16_f8<e8m0(-kF8Act - kF8Lo), e8m0(-kF8Wgt)>(acc[I][j], al8, cat8(w8[j][0], w8[j][1]), 1);
+#else
           for (int j = 0; j < TN; ++j) acc[I][j] = mfma32_f8<e8m0(-kF8Act - kF8Lo), e8m0(-kF8Wgt)>(al8, cat8(w8[j][0], w8[j][1]), acc[I][j]);
+#endif
           __builtin_amdgcn_sched_barrier(0);
         } else {
           lgkm_wait<(I + 1 < TM ? 2 : 0)>(ay[0], ay[1]);    // younger: X(I + 1)
           __builtin_amdgcn_sched_barrier(0);
           const i32x8 al8 = cat8(ay[0], ay[1]);
 #pragma unroll
+#ifdef AWT_DIAG_MFMA16
+          for (int j = 0; j < TN; ++j) diag_mfma16_f8<e8m0(-kF8Act - kF8Lo), e8m0(-kF8Wgt)>(acc[I][j], al8, cat8(w8[j][0], w8[j][1]), 1);
+#else
           for (int j = 0; j < TN; ++j) acc[I][j] = mfma32_f8<e8m0(-kF8Act - kF8Lo), e8m0(-kF8Wgt)>(al8, cat8(w8[j][0], w8[j][1]), acc[I][j]);
+#endif
           __builtin_amdgcn_sched_barrier(0);
           if constexpr (I + 1 < TM) read_y(std::integral_constant<int, I + 1>{});
         }
