@@ -31,7 +31,8 @@ struct BwdArgs {
   const bf16_t *q_hi, *q_lo, *k_hi, *k_lo, *v_hi, *v_lo;   // head-major [B, H, S, 64]
   const bf16_t *do_hi, *do_lo;                              // row-major [B*S, H*64]
   const float* lse2;                                        // [B, H, S]
-  const float* delta;                                       // [B, H, S]
+  float* delta;                                             // [B, H, S]: written by the dq launch (rowsum(dO * O), from o_hi / o_lo), read by the dk / dv launch
+  const bf16_t *o_hi, *o_lo;                                // the forward's attention output, row-major like dO
   bf16_t *g_hi, *g_lo;                                      // row-major [B*S, 3*H*64]: dq | dk | dv
   int B, H, S; float qscale;
 };
@@ -166,7 +167,21 @@ __global__ __launch_bounds__(kThreads, 2) void attention_bwd_kernel(BwdArgs a) {
     t1 = TileSrc{a.k_hi, a.k_lo, head_off, 64};
     t2 = TileSrc{a.v_hi, a.v_lo, head_off, 64};
     lse_l = a.lse2[(int64_t)bh * a.S + lrow];
-    delta_l = a.delta[(int64_t)bh * a.S + lrow];
+    {   // delta = rowsum(dO * O) of the lane's query row: each lane half holds 32 of its 64 elements (the fragments just loaded); the dk / dv launch reads it back
+      bf16x8 oh[4], ol[4];
+      load_lane_frags(a.o_hi, a.o_lo, rm_off + (int64_t)lrow * d + half * 8, TERMS == 3, oh, ol);
+      float part = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float dv = bf16_to_f32((bf16_t)l2h[ks][j]) + (TERMS == 3 ? bf16_to_f32((bf16_t)l2l[ks][j]) : 0.f);
+          const float ov = bf16_to_f32((bf16_t)oh[ks][j]) + (TERMS == 3 ? bf16_to_f32((bf16_t)ol[ks][j]) : 0.f);
+          part += dv * ov;
+        }
+      delta_l = part + __shfl_xor(part, 32);
+      if (half == 0 && l0 + ll_ < a.S) a.delta[(int64_t)bh * a.S + lrow] = delta_l;
+    }
   } else {                 // lanes: keys.  L1 = k, L2 = v; tiles: Q, dO
     load_lane_frags(a.k_hi, a.k_lo, head_off + (int64_t)lrow * 64 + half * 8, TERMS == 3, l1h, l1l);
     load_lane_frags(a.v_hi, a.v_lo, head_off + (int64_t)lrow * 64 + half * 8, TERMS == 3, l2h, l2l);
@@ -248,33 +263,6 @@ __global__ __launch_bounds__(kThreads, 2) void attention_bwd_kernel(BwdArgs a) {
   }
 }
 
-// delta[b, h, s] = sum_e dO[b*S+s, h*64+e] * O[b*S+s, h*64+e]   (hi + lo planes reconstructed in fp32)
-__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* do_hi, const bf16_t* do_lo, const bf16_t* o_hi, const bf16_t* o_lo,
-                                                         float* delta, int B, int H, int S) {
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;     // one thread per 8 elements; 8 threads per (row, head)
-  const int d = H * 64;
-  const int64_t total = (int64_t)B * S * d / 8;
-  float acc = 0.f;
-  if (idx < total) {
-    const bf16x8 dh = reinterpret_cast<const bf16x8*>(do_hi)[idx], oh = reinterpret_cast<const bf16x8*>(o_hi)[idx];
-    bf16x8 dl = {}, ol = {};
-    if (do_lo) { dl = reinterpret_cast<const bf16x8*>(do_lo)[idx]; ol = reinterpret_cast<const bf16x8*>(o_lo)[idx]; }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float dv = bf16_to_f32((bf16_t)dh[j]) + bf16_to_f32((bf16_t)dl[j]);
-      const float ov = bf16_to_f32((bf16_t)oh[j]) + bf16_to_f32((bf16_t)ol[j]);
-      acc += dv * ov;
-    }
-  }
-  acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4);
-  if (idx < total && (threadIdx.x & 7) == 0) {
-    const int64_t e0 = idx * 8;
-    const int64_t row = e0 / d; const int h = (int)((e0 - row * d) >> 6);
-    const int64_t b = row / S, s = row - b * S;
-    delta[(b * H + h) * S + s] = acc;
-  }
-}
-
 // GT = products of the GRADIENT contractions (dp, dq, dk, dv): TERMS, or 1 with TERMS = 3 (the opt-in bf16 backward: the
 // scores are still recomputed in split-bf16, because p = exp2(s - lse) has to reproduce the forward's probabilities)
 template <int TERMS, int MODE, int GT>
@@ -299,11 +287,8 @@ int launch_attention_bwd(awt_ctx* c, const bf16_t* q_hi, const bf16_t* q_lo, con
   AWT_REQUIRE(q_hi && k_hi && v_hi && o_hi && do_hi && lse2 && delta && g_hi, AWT_ERR_INVALID, "attention_bwd: null argument");
   AWT_REQUIRE(terms == 1 || (q_lo && k_lo && v_lo && o_lo && do_lo && g_lo), AWT_ERR_INVALID, "attention_bwd: lo planes required");
   ProfScope prof(c, AWT_PROF_ATTENTION_BWD, s, 14.0 * (double)B * H * (double)S * S * 64);   // 7 products (s and dp are formed twice)
-  const int64_t n8 = (int64_t)B * S * H * 64 / 8;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, do_hi, terms == 3 ? do_lo : nullptr, o_hi,
-                     terms == 3 ? o_lo : nullptr, delta, B, H, S);
-  AWT_HIP_CHECK(hipGetLastError());
-  BwdArgs a{q_hi, q_lo, k_hi, k_lo, v_hi, v_lo, do_hi, do_lo, lse2, delta, g_hi, terms == 3 ? g_lo : nullptr, B, H, S, qscale};
+  // delta = rowsum(dO * O) is formed by the dq launch (its lanes hold the dO rows already) and read back by the dk / dv launch that follows it on the stream
+  BwdArgs a{q_hi, q_lo, k_hi, k_lo, v_hi, v_lo, do_hi, do_lo, lse2, delta, o_hi, terms == 3 ? o_lo : nullptr, g_hi, terms == 3 ? g_lo : nullptr, B, H, S, qscale};
   int rc = terms == 1 ? launch_mode<1, MODE_DQ, 1>(a, s) : (grad_terms == 3 ? launch_mode<3, MODE_DQ, 3>(a, s) : launch_mode<3, MODE_DQ, 1>(a, s));
   if (rc) return rc;
   return terms == 1 ? launch_mode<1, MODE_DKV, 1>(a, s) : (grad_terms == 3 ? launch_mode<3, MODE_DKV, 3>(a, s) : launch_mode<3, MODE_DKV, 1>(a, s));
