@@ -316,7 +316,12 @@ int awt_op_attention_small_backward(awt_ctx* c, const float* q, int ldq, const f
  * "gemm_gm": row panels per tile-order group (0 = default).  "attn_shape": workgroup shape of the f16f8 attention kernel, 0 =
  * automatic; 1..5 keep the e4m3 cross terms of P V (plain 4x32 / 4x64 / 6x32 queries, software-pipelined 4 / 8 waves), 6 / 7 =
  * software-pipelined 4 / 8 waves with P V as one fp16 product (what 0 selects for inference).  Only the last choice changes
- * results (within the tolerances of DESIGN.md section 3); every other value is bit-neutral. */
+ * results (within the tolerances of DESIGN.md section 3); every other value is bit-neutral.
+ * "gemm_pp": the persistent 256 x 256 eight-wave "ping-pong" f16f8 GEMM (csrc/gemm_pp.h: both operands by LDS-DMA, interleaved-line
+ * activations, one workgroup per CU walking its tiles): 0 = off (default: on the encoder's shapes it ties the 128 x 256 kernels end to
+ * end), 1 = automatic (inference launches of >= 256 tiles on weights that are not fp16-exact), 2 = wherever it applies (N % 256 == 0,
+ * K % 64 == 0, K >= 128, no adapter; also awt_op_linear).  Same accumulation order per output, so results differ from the default
+ * tiling only by the e4m3 cross terms' grouping (<= 1e-4 on hidden states). */
 int awt_tuning_set(const char* key, int value);
 
 /* ------------------------------------------------------------------------------------------------------

@@ -30,7 +30,7 @@ def _stale(target: str, deps) -> bool:
 
 def _compile(src: str, force: bool) -> str:
     obj = os.path.join(OBJ, src.replace(".hip", ".o"))
-    deps = [os.path.join(CSRC, src), os.path.join(CSRC, "common.h"), os.path.join(CSRC, "comm.h"), os.path.join(HERE, "..", "include", "awt.h")]
+    deps = [os.path.join(CSRC, src), os.path.join(CSRC, "common.h"), os.path.join(CSRC, "comm.h"), os.path.join(CSRC, "gemm_pp.h"), os.path.join(HERE, "..", "include", "awt.h")]
     if force or _stale(obj, deps):
         cmd = [HIPCC, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -38,6 +38,7 @@ struct Attn8Args {
   bf16_t* o16; uint8_t *o8, *ol8; float* o_f32;  // output: f16f8 activation planes [B*S, H*64] or fp32
   float* lse;
   int B, H, S;
+  char* o_ilv;                                   // ... or the same activation as interleaved lines (common.h Act::ilv), when set
 };
 
 __device__ __forceinline__ int swz16(int row) { return (row >> 1) & 7; }        // fp16 planes: 128-byte rows, 8 chunks
@@ -298,6 +299,7 @@ __global__ __launch_bounds__(64 * NW, (QT == 1 && NW == 6) ? 3 : 2) void attenti
           } else {
             uint2 h16; unsigned hi8, lo8;
             f16f8x4<kF8Act>(v, h16, hi8, lo8);
+            if (a.o_ilv) { store_ilv4(a.o_ilv, row + e, h16, hi8, lo8); continue; }
             *reinterpret_cast<uint2*>(a.o16 + row + e) = h16;
             if (a.o8) *reinterpret_cast<unsigned*>(a.o8 + row + e) = hi8;
             *reinterpret_cast<unsigned*>(a.ol8 + row + e) = lo8;
@@ -665,6 +667,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f16f8_pipe_kernel(Attn8A
         } else {
           uint2 h16; unsigned hi8, lo8;
           f16f8x4<kF8Act>(v, h16, hi8, lo8);
+          if (a.o_ilv) { store_ilv4(a.o_ilv, row + e, h16, hi8, lo8); continue; }
           *reinterpret_cast<uint2*>(a.o16 + row + e) = h16;
           if (a.o8) *reinterpret_cast<unsigned*>(a.o8 + row + e) = hi8;
           *reinterpret_cast<unsigned*>(a.ol8 + row + e) = lo8;
@@ -703,12 +706,14 @@ void awt_attn_force_shape(int v) { g_attn_shape = v; }
 bool attention_f16f8_reads_v8(bool with_lse) { return with_lse || (g_attn_shape >= 1 && g_attn_shape <= 5); }
 
 int launch_attention_f16f8(awt_ctx* c, const F8Planes& q, const F8Planes& k, const F8Planes& v, const F8Planes& o, float* o_f32,
-                           float* lse, int B, int H, int S, hipStream_t s) {
+                           float* lse, int B, int H, int S, hipStream_t s, char* o_ilv) {
   AWT_REQUIRE(B > 0 && H > 0 && S > 0, AWT_ERR_INVALID, "attention: bad shape");
   AWT_REQUIRE(q.p16 && q.hi8 && q.lo8 && k.p16 && k.hi8 && k.lo8 && v.p16 && v.hi8 && v.lo8, AWT_ERR_INVALID, "attention (f16f8): null plane");
   // (v.hi8 / v.lo8 are only dereferenced by the forms attention_f16f8_reads_v8() names; the encoder does not fill them otherwise)
-  AWT_REQUIRE(o_f32 || (o.p16 && o.lo8), AWT_ERR_INVALID, "attention (f16f8): null output plane (hi8 may be null: not consumed)");
+  AWT_REQUIRE(o_f32 || o_ilv || (o.p16 && o.lo8), AWT_ERR_INVALID, "attention (f16f8): null output plane (hi8 may be null: not consumed)");
+  AWT_REQUIRE(!o_ilv || (H * 64) % 32 == 0, AWT_ERR_INVALID, "attention (f16f8): interleaved-line output needs whole 32-element lines per row");
   Attn8Args a{q.p16, k.p16, v.p16, q.hi8, q.lo8, k.hi8, k.lo8, v.hi8, v.lo8, o.p16, o.hi8, o.lo8, o_f32, lse, B, H, S};
+  a.o_ilv = o_f32 ? nullptr : o_ilv;
   ProfScope prof(c, AWT_PROF_ATTENTION, s, 4.0 * (double)B * H * (double)S * S * 64);
   // shapes (awt_tuning_set "attn_shape"): 0 = auto; 1 = 4 waves x 32 queries; 2 = 4 waves x 64 queries; 3 = 6 waves x 32 queries
   // (three waves per SIMD: one wave's softmax VALU work runs beside the others' MFMAs); 4 / 5 = software-pipelined, 4 / 8 waves,

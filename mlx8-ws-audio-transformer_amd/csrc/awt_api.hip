@@ -50,6 +50,11 @@ extern "C" int awt_tuning_set(const char* key, int value) {
     awt_gemm_set_gm(value);
     return AWT_OK;
   }
+  if (!strcmp(key, "gemm_pp")) {
+    AWT_REQUIRE(value >= 0 && value <= 2, AWT_ERR_INVALID, "tuning_set: gemm_pp must be 0 (off, default), 1 (automatic) or 2 (wherever supported)");
+    awt_gemm_set_pp_mode(value);
+    return AWT_OK;
+  }
   if (!strcmp(key, "attn_shape")) {
     AWT_REQUIRE(value >= 0 && value <= 9, AWT_ERR_INVALID, "tuning_set: attn_shape must be 0 (auto) or 1 .. 9");
     awt_attn_force_shape(value);
@@ -162,6 +167,7 @@ struct Planes {  // a weight matrix as operand planes owned by the library: hi (
   // PREC_F16F8 inference: one device flag per separately uploaded row block (q | k | v): "a weight of this block is not exactly fp16";
   // exact16 = no flag set = the lo8 image is all zero and the GEMM drops that cross term (gemm.hip, WX)
   int* d_inexact = nullptr; bool exact16 = false;
+  char* pp = nullptr;   // PREC_F16F8 inference: the same matrix in the packed region image of the ping-pong GEMM (gemm_pp.h), N % 256 == 0 only
 };
 struct Linear {
   Planes w; float* bias = nullptr; int N = 0, K = 0;
@@ -273,6 +279,8 @@ Workspace carve(const awt_encoder* e, char* base, int Bc) {
   for (size_t p = 0; p < P; ++p) w.a1[p] = (bf16_t*)take(Mt * conv1_k(c.n_mels) * 2);
   for (size_t p = 0; p < P; ++p) w.h1[p] = (bf16_t*)take(Mt * d * 2);
   w.bytes = std::max(off, layer_end);
+  // the ping-pong GEMM reads whole 256-row panels of its activation: up to 255 rows past the last buffer's end (never stored)
+  if (e->prec == PREC_F16F8 && !c.training) w.bytes += align_up((size_t)256 * std::max(f, (size_t)conv1_k(c.n_mels)) * 4);
   return w;
 }
 
@@ -292,7 +300,9 @@ Act act_offset(const Act& a, int64_t elems) {
   r.lo8 = a.lo8 ? a.lo8 + elems : nullptr;
   return r;
 }
-void set_out(GemmOut& o, const Act& a) { o.hi = a.p16; o.lo = a.lo16; o.hi8 = a.hi8; o.lo8 = a.lo8; }
+void set_out(GemmOut& o, const Act& a) { o.hi = a.p16; o.lo = a.lo16; o.hi8 = a.hi8; o.lo8 = a.lo8; o.ilv = a.ilv; }
+// the same buffer pair as one interleaved-line image (Act::ilv): the two 2-byte planes are adjacent, 4 bytes per element in all
+Act make_ilv(bf16_t* p0) { Act a; a.ilv = (char*)p0; return a; }
 
 GemmSeg seg_plain(const Act& a, int64_t lda, const Planes& w, int64_t wcol, int K, int M) {
   GemmSeg s{};
@@ -301,6 +311,7 @@ GemmSeg seg_plain(const Act& a, int64_t lda, const Planes& w, int64_t wcol, int 
   s.w_ksteps = (int)(w.ld / 32); s.w_k0 = (int)(wcol / 32); s.K = K;
   s.rows_out = M; s.rows_in = M; s.row_mul = 1; s.row_add = 0;
   s.w_exact16 = w.exact16 ? 1 : 0;
+  s.a_ilv = a.ilv; s.w_pp = w.pp;
   return s;
 }
 GemmSeg seg_plain(const bf16_t* a_hi, const bf16_t* a_lo, int64_t lda, const Planes& w, int64_t wcol, int K, int M) {   // bf16 planes (backward pass)
@@ -329,6 +340,22 @@ int linear_with_lora(awt_encoder* e, bf16_t* const u[2], bf16_t* const in[2], in
   out.bias = lin.bias;
   out.n_valid = lin.N;
   return launch_gemm(e->ctx, M, lin.N, segs, nseg, terms, epi, out, s);
+}
+
+// y = x W^T on the persistent ping-pong kernel: x as interleaved lines (make_ilv), W's packed image; no adapter
+int linear_pp(awt_encoder* e, bf16_t* in0, const Linear& lin, int M, GemmEpilogue epi, GemmOut out, hipStream_t s) {
+  GemmSeg sg = seg_plain(make_ilv(in0), lin.K, lin.w, 0, lin.K, M);
+  out.bias = lin.bias;
+  out.n_valid = lin.N;
+  return launch_gemm_pp(e->ctx, M, lin.N, sg, epi, out, s);
+}
+// whether this linear of an inference forward over M rows runs on the ping-pong kernel (tuning knob "gemm_pp": 0 never, 1 automatic, 2 wherever
+// it can): automatic = a launch of at least one 256 x 256 tile per CU, and not the fp16-exact weights the one-cross-term GEMM (gemm.hip, WX) is faster on
+bool use_pp(const awt_encoder* e, const Linear& lin, const LoraGroup& lg, int M, int epi) {
+  const int mode = awt_gemm_pp_mode();
+  if (mode == 0 || e->prec != PREC_F16F8 || !lin.w.pp || lg.active || !gemm_pp_supported(M, lin.N, lin.K, epi)) return false;
+  if (mode == 2) return true;
+  return !lin.w.exact16 && (int64_t)((M + 255) / 256) * (lin.N / 256) >= 256;
 }
 
 // Per-layer activation buffers.  Inference: every layer reuses one set (residual stream updated in place).
@@ -419,20 +446,27 @@ int encoder_layer(awt_encoder* e, Layer& L, const LayerBufs& b, int Bc, bool sav
   const int S = c.n_ctx, d = c.d_model, f = c.ffn_dim, H = c.n_heads, terms = e->prec;
   const int M = Bc * S;
   const int64_t plane = (int64_t)M * d;
+  // which of the four linears run on the persistent ping-pong kernel (inference only): their inputs are then written as interleaved lines by the
+  // producer (LayerNorm, the attention epilogue, fc1's GELU epilogue) instead of as three planes -- same bytes, same buffers
+  const bool pp_qkv = !save && use_pp(e, L.qkv, L.lq, M, EPI_QKV), pp_out = !save && use_pp(e, L.out, L.lo_, M, EPI_F32_RESID);
+  const bool pp_fc1 = !save && use_pp(e, L.fc1, L.l1, M, EPI_BF16_GELU), pp_fc2 = pp_fc1 && use_pp(e, L.fc2, L.l2, M, EPI_F32_RESID);
   // an activation whose only consumer is a GEMM on fp16-exact weights (gemm.hip, WX) needs no hi8 image: the producers skip that plane
   auto feeds = [&](Act a, const Linear& lin, const LoraGroup& lg) { if (terms == PREC_F16F8 && lin.w.exact16 && !lg.active) a.hi8 = nullptr; return a; };
-  const Act aqkv = make_act(b.qkv[0], b.qkv[1], 3 * (size_t)plane, terms), aatt = feeds(make_act(b.att[0], b.att[1], (size_t)plane, terms), L.out, L.lo_);
-  int rc = launch_layernorm(e->ctx, b.x_in, L.ln1_g, L.ln1_b, M, d, 1e-5f, nullptr, feeds(make_act(b.ln1[0], b.ln1[1], (size_t)plane, terms), L.qkv, L.lq), terms, s); if (rc) return rc;
+  const Act aqkv = make_act(b.qkv[0], b.qkv[1], 3 * (size_t)plane, terms);
+  const Act aatt = pp_out ? make_ilv(b.att[0]) : feeds(make_act(b.att[0], b.att[1], (size_t)plane, terms), L.out, L.lo_);
+  int rc = launch_layernorm(e->ctx, b.x_in, L.ln1_g, L.ln1_b, M, d, 1e-5f, nullptr,
+                            pp_qkv ? make_ilv(b.ln1[0]) : feeds(make_act(b.ln1[0], b.ln1[1], (size_t)plane, terms), L.qkv, L.lq), terms, s); if (rc) return rc;
   {
     GemmOut o{}; set_out(o, aqkv); o.scale = 0.125f * 1.4426950408889634f;   // head_dim^-1/2 and log2(e): see attention.hip
     o.S = S; o.H = H; o.plane_stride = plane;
     o.skip_v8 = terms == PREC_F16F8 && !attention_f16f8_reads_v8(save);
-    rc = linear_with_lora(e, b.u, b.ln1, d, L.qkv, L.lq, M, EPI_QKV, o, s); if (rc) return rc;
+    rc = pp_qkv ? linear_pp(e, b.ln1[0], L.qkv, M, EPI_QKV, o, s) : linear_with_lora(e, b.u, b.ln1, d, L.qkv, L.lq, M, EPI_QKV, o, s);
+    if (rc) return rc;
   }
   if (terms == PREC_F16F8) {
     const Act ak = act_offset(aqkv, plane), av = act_offset(aqkv, 2 * plane);
     rc = launch_attention_f16f8(e->ctx, F8Planes{aqkv.p16, aqkv.hi8, aqkv.lo8}, F8Planes{ak.p16, ak.hi8, ak.lo8}, F8Planes{av.p16, av.hi8, av.lo8},
-                                F8Planes{aatt.p16, aatt.hi8, aatt.lo8}, nullptr, save ? b.lse : nullptr, Bc, H, S, s);
+                                F8Planes{aatt.p16, aatt.hi8, aatt.lo8}, nullptr, save ? b.lse : nullptr, Bc, H, S, s, aatt.ilv);
   } else {
     rc = launch_attention(e->ctx, b.qkv[0], b.qkv[1], b.qkv[0] + plane, b.qkv[1] ? b.qkv[1] + plane : nullptr, b.qkv[0] + 2 * plane,
                           b.qkv[1] ? b.qkv[1] + 2 * plane : nullptr, b.att[0], b.att[1], nullptr, save ? b.lse : nullptr, Bc, H, S, terms, s);
@@ -440,7 +474,8 @@ int encoder_layer(awt_encoder* e, Layer& L, const LayerBufs& b, int Bc, bool sav
   if (rc) return rc;
   {
     GemmOut o{}; o.f32 = b.x_mid; o.resid = b.x_in; o.ldo = d;
-    rc = linear_with_lora(e, b.uo, b.att, d, L.out, L.lo_, M, EPI_F32_RESID, o, s); if (rc) return rc;
+    rc = pp_out ? linear_pp(e, b.att[0], L.out, M, EPI_F32_RESID, o, s) : linear_with_lora(e, b.uo, b.att, d, L.out, L.lo_, M, EPI_F32_RESID, o, s);
+    if (rc) return rc;
   }
   if (save && e->mlp_f8) {   // backward_terms = 5: the MLP of the training step in the f16f8 operand format (no fc1 / fc2 adapters in this mode)
     const Act aln2 = make_act(b.ln2[0], b.ln2[1], (size_t)plane, PREC_F16F8), aff = make_act(b.ff[0], b.ff[1], (size_t)M * f, PREC_F16F8);
@@ -452,13 +487,16 @@ int encoder_layer(awt_encoder* e, Layer& L, const LayerBufs& b, int Bc, bool sav
     GemmOut o2{}; o2.f32 = b.x_out; o2.resid = b.x_mid; o2.ldo = d; o2.n_valid = d; o2.bias = L.fc2.bias;
     return launch_gemm(e->ctx, M, d, &s2, 1, PREC_F16F8, EPI_F32_RESID, o2, s);
   }
-  rc = launch_layernorm(e->ctx, b.x_mid, L.ln2_g, L.ln2_b, M, d, 1e-5f, nullptr, feeds(make_act(b.ln2[0], b.ln2[1], (size_t)plane, terms), L.fc1, L.l1), terms, s); if (rc) return rc;
+  rc = launch_layernorm(e->ctx, b.x_mid, L.ln2_g, L.ln2_b, M, d, 1e-5f, nullptr,
+                        pp_fc1 ? make_ilv(b.ln2[0]) : feeds(make_act(b.ln2[0], b.ln2[1], (size_t)plane, terms), L.fc1, L.l1), terms, s); if (rc) return rc;
   {
-    GemmOut o{}; set_out(o, feeds(make_act(b.ff[0], b.ff[1], (size_t)M * f, terms), L.fc2, L.l2)); o.ldo = f; o.hi2 = b.pre[0]; o.lo2 = b.pre[1];
-    rc = linear_with_lora(e, b.u1, b.ln2, d, L.fc1, L.l1, M, save ? EPI_BF16_GELU_SAVE : EPI_BF16_GELU, o, s); if (rc) return rc;
+    GemmOut o{}; set_out(o, pp_fc2 ? make_ilv(b.ff[0]) : feeds(make_act(b.ff[0], b.ff[1], (size_t)M * f, terms), L.fc2, L.l2)); o.ldo = f; o.hi2 = b.pre[0]; o.lo2 = b.pre[1];
+    rc = pp_fc1 ? linear_pp(e, b.ln2[0], L.fc1, M, EPI_BF16_GELU, o, s)
+                : linear_with_lora(e, b.u1, b.ln2, d, L.fc1, L.l1, M, save ? EPI_BF16_GELU_SAVE : EPI_BF16_GELU, o, s);
+    if (rc) return rc;
   }
   GemmOut o{}; o.f32 = b.x_out; o.resid = b.x_mid; o.ldo = d;
-  return linear_with_lora(e, b.u2, b.ff, f, L.fc2, L.l2, M, EPI_F32_RESID, o, s);
+  return pp_fc2 ? linear_pp(e, b.ff[0], L.fc2, M, EPI_F32_RESID, o, s) : linear_with_lora(e, b.u2, b.ff, f, L.fc2, L.l2, M, EPI_F32_RESID, o, s);
 }
 
 int forward_chunk(awt_encoder* e, const float* mel, int Bc, float* hidden, char* ws_base, hipStream_t s) {
@@ -550,6 +588,9 @@ extern "C" int awt_encoder_create(awt_ctx* c, const awt_encoder_cfg* cfg, awt_en
     if (!rc) rc = alloc_linear(e, &L.fc2, d, f);
     if ((e->prec == PREC_F16F8 || e->prec == PREC_F16X3) && !cfg->training)   // four zero-initialised "not fp16-exact" flags per projection matrix (set_weight)
       for (Linear* lin : {&L.qkv, &L.out, &L.fc1, &L.fc2}) if (!rc) rc = dev_alloc(e, (void**)&lin->w.d_inexact, 4 * sizeof(int));
+    if (e->prec == PREC_F16F8 && !cfg->training)     // the packed images of the ping-pong GEMM (a second copy of each weight: 4 bytes per element)
+      for (Linear* lin : {&L.qkv, &L.out, &L.fc1, &L.fc2})
+        if (!rc && lin->N % 256 == 0 && lin->K % 64 == 0 && lin->K >= 128) rc = dev_alloc(e, (void**)&lin->w.pp, gemm_pp_weight_bytes(lin->N, lin->K));
     if (cfg->training) {
       if (!rc) rc = alloc_planes(e, &L.qkvT, d, 3 * d);
       if (!rc) rc = alloc_planes(e, &L.outT, d, d);
@@ -624,6 +665,7 @@ extern "C" int awt_encoder_set_weight(awt_encoder* e, const char* name, const fl
             rc = awt_fail(AWT_ERR_HIP, "set_weight: flag read-back failed");
           if (!rc) pl.exact16 = !(host[0] | host[1] | host[2] | host[3]);
         } else if (!rc) rc = pack(p.lin->w, p.N, p.K, 1, p.row_off, 0);
+        if (!rc && p.lin->w.pp) rc = launch_pack_weight_pp(e->ctx, data, p.N, p.K, p.row_off, p.lin->w.pp, s);
         if (!rc && c.training)   // W^T: [K, N_total], this projection's columns start at row_off
           rc = launch_pack_weight_t(e->ctx, data, p.N, p.K, p.wT->ld, 0, p.row_off, 1.0f, p.wT->hi, p.wT->lo, s);
         if (!rc && e->mlp_f8 && p.wT8) {   // the same W^T [K, N] in the f16f8 weight format: transposed into the scratch matrix, then packed like a forward weight
@@ -771,6 +813,18 @@ extern "C" int awt_op_linear(awt_ctx* c, const float* x, const float* w, const f
     GemmOut o6{}; o6.f32 = y; o6.ldo = N; o6.bias = bias; o6.n_valid = N;
     return launch_gemm(c, M, N, &sg6, 1, terms, EPI_F32, o6, s);
 #endif
+  }
+  if (terms == PREC_F16F8 && awt_gemm_pp_mode() == 2 && gemm_pp_supported(M, N, K, EPI_F32)) {
+    // the persistent ping-pong kernel (tuning knob "gemm_pp" = 2): x as interleaved lines over the two x planes' space (its 256-row panel reads beyond M
+    // stay inside the workspace: the packed weight image of N >= 256 rows follows), the weight in the packed region image over the two w planes' space
+    Act ai; ai.ilv = (char*)xh;
+    int rcp = launch_split_planes(c, x, (int64_t)M * K, 1.0f, terms, kF8Act, nullptr, nullptr, nullptr, nullptr, s, ai.ilv); if (rcp) return rcp;
+    if (hipMemsetAsync(wh, 0, gemm_pp_weight_bytes(N, K), s) != hipSuccess) return awt_fail(AWT_ERR_HIP, "op_linear: weight image reset failed");
+    rcp = launch_pack_weight_pp(c, w, N, K, 0, (char*)wh, s); if (rcp) return rcp;
+    Planes pwp; pwp.pp = (char*)wh; pwp.rows = N; pwp.ld = K;
+    GemmSeg sgp = seg_plain(ai, K, pwp, 0, K, M);
+    GemmOut op{}; op.f32 = y; op.ldo = N; op.bias = bias; op.n_valid = N;
+    return launch_gemm_pp(c, M, N, sgp, EPI_F32, op, s);
   }
   const Act ax = make_act(xh, xl, (size_t)M * K, terms);
   int rc = launch_split_planes(c, x, (int64_t)M * K, 1.0f, terms, kF8Act, xh, xl, ax.hi8, ax.lo8, s); if (rc) return rc;

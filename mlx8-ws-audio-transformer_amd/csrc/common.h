@@ -208,14 +208,25 @@ __host__ __device__ __forceinline__ int64_t w8_index(int n, int k, int ktiles64)
   return (((int64_t)nt * ktiles64 + kt) * 64 + (h * 32 + r)) * 32 + b;
 }
 
-// An activation matrix as MFMA operand planes: p16 (bf16 or fp16) + lo16 (split modes) or + hi8 / lo8 (f16f8)
-struct Act { bf16_t* p16 = nullptr; bf16_t* lo16 = nullptr; uint8_t* hi8 = nullptr; uint8_t* lo8 = nullptr; };
+// An activation matrix as MFMA operand planes: p16 (bf16 or fp16) + lo16 (split modes) or + hi8 / lo8 (f16f8).
+// ilv (PREC_F16F8 only, instead of the three planes): the INTERLEAVED-LINE image the ping-pong GEMM (gemm_pp.h) stages by whole cache
+// lines -- a dense [M][K] matrix, K % 32 == 0, as [M][K / 32] lines of 128 bytes = the 32 elements' fp16 | hi8 | lo8 (64 + 32 + 32 bytes),
+// so that element offset `off` (a multiple of 4) lives in line off >> 5 at group g = (off & 31) >> 2: fp16 bytes 8 g, hi8 64 + 4 g, lo8 96 + 4 g.
+struct Act { bf16_t* p16 = nullptr; bf16_t* lo16 = nullptr; uint8_t* hi8 = nullptr; uint8_t* lo8 = nullptr; char* ilv = nullptr; };
+__device__ __forceinline__ void store_ilv4(char* ilv, int64_t off, uint2 h16, unsigned hi8, unsigned lo8) {
+  char* line = ilv + (off >> 5) * 128;
+  const int g = (int)(off & 31) >> 2;
+  *reinterpret_cast<uint2*>(line + g * 8) = h16;
+  *reinterpret_cast<unsigned*>(line + 64 + g * 4) = hi8;
+  *reinterpret_cast<unsigned*>(line + 96 + g * 4) = lo8;
+}
 // four consecutive elements at element offset `off` (a multiple of 4) in the planes of precision PREC; S = e4m3 exponent
 template <int PREC, int S = kF8Act>
 __device__ __forceinline__ void store_act4(const Act& o, int64_t off, const float (&v)[4]) {
   if constexpr (PREC == PREC_F16F8) {
     uint2 h16; unsigned hi8, lo8;
     f16f8x4<S>(v, h16, hi8, lo8);
+    if (o.ilv) { store_ilv4(o.ilv, off, h16, hi8, lo8); return; }
     *reinterpret_cast<uint2*>(o.p16 + off) = h16;
     if (o.hi8) *reinterpret_cast<unsigned*>(o.hi8 + off) = hi8;      // null: every consumer runs the fp16-exact-weight GEMM, which never reads this image
     *reinterpret_cast<unsigned*>(o.lo8 + off) = lo8;
@@ -290,6 +301,9 @@ struct GemmSeg {
   // with the same lda, weights in w8_index order; w_ksteps / w_k0 still count 32-deep steps of the matrix / of the segment start)
   const uint8_t* a8; const uint8_t* al8; const uint8_t* w8; const uint8_t* wl8;
   int w_exact16;                                         // PREC_F16F8: every weight of the segment is exactly representable in fp16 (its lo8 image is zero)
+  // ping-pong kernel (launch_gemm_pp, PREC_F16F8): the activation as interleaved lines (Act::ilv, row pitch lda * 4 bytes) and the weight matrix in
+  // the packed region image of gemm_pp.h (launch_pack_weight_pp); both null = the segment is only for the kernels above
+  const char* a_ilv; const char* w_pp;
   int K;                                                 // multiple of the kernel's BK
   // source row of output row m:  (m / rows_out) * rows_in + (m % rows_out) * row_mul + row_add ; rows outside
   // [0, rows_in) of their group read as zeros (the conv stem's padding).  Plain GEMM: rows_out = rows_in = M.
@@ -311,6 +325,7 @@ struct GemmOut {
   float* f32; const float* resid; int64_t ldo;
   bf16_t* hi; bf16_t* lo;                 // lo may be null when terms == 1
   uint8_t* hi8; uint8_t* lo8;             // PREC_F16F8: the e4m3 planes of the output (hi = its fp16 plane); same offsets as hi
+  char* ilv;                              // PREC_F16F8, EPI_BF16 / EPI_BF16_GELU of launch_gemm_pp: the output as interleaved lines instead (Act::ilv; dense [M][ldo])
   bf16_t* hi2; bf16_t* lo2;               // EPI_BF16_GELU_SAVE: pre-activation planes (same ldo)
   const bf16_t* pre_hi; const bf16_t* pre_lo;   // EPI_BF16_DGELU: saved pre-activation planes (same ldo)
   const float* bias;                      // [N] or null
@@ -325,6 +340,15 @@ struct GemmOut {
 // `prec`: PREC_* of the operands (and of plane outputs)
 int launch_gemm(awt_ctx* c, int M, int N, const GemmSeg* segs, int nseg, int prec, GemmEpilogue epi, const GemmOut& out,
                 hipStream_t s);
+// The persistent 256 x 256 ping-pong kernel (gemm_pp.h) for one plain K segment in PREC_F16F8: seg.a_ilv / seg.w_pp, N % 256 == 0, K % 64 == 0, K >= 128,
+// the activation buffer readable for ceil(M / 256) * 256 rows.  Epilogues: EPI_F32, EPI_F32_RESID, EPI_BF16, EPI_BF16_GELU, EPI_QKV.
+bool gemm_pp_supported(int M, int N, int K, int epi);
+int launch_gemm_pp(awt_ctx* c, int M, int N, const GemmSeg& seg, GemmEpilogue epi, const GemmOut& out, hipStream_t s);
+size_t gemm_pp_weight_bytes(int N, int K);          // packed image of an [N, K] weight (N padded to 256)
+// dst rows row_off .. row_off + N - 1 of a packed [Ntot, K] image = src [N, K] fp32 (f16f8 planes, kF8Wgt exponents); padding rows stay as allocated (zero)
+int launch_pack_weight_pp(awt_ctx* c, const float* src, int N, int K, int row_off, char* dst, hipStream_t s);
+int awt_gemm_pp_mode();                             // tuning knob "gemm_pp": 0 off (default), 1 automatic, 2 wherever supported
+void awt_gemm_set_pp_mode(int v);
 
 // out_f32 (the final layer_norm) or operand planes of precision `prec`
 int launch_layernorm(awt_ctx* c, const float* x, const float* gamma, const float* beta, int M, int d, float eps,
@@ -338,9 +362,9 @@ int launch_split_f32(awt_ctx* c, const float* x, int64_t n, float scale, bf16_t*
 // lo8 = e4m3((x - fp16(x)) 2^(f8_exp + 11))
 struct F8Planes { bf16_t* p16; uint8_t* hi8; uint8_t* lo8; };
 int launch_split_planes(awt_ctx* c, const float* x, int64_t n, float scale, int prec, int f8_exp, bf16_t* p16, bf16_t* lo16, uint8_t* hi8,
-                        uint8_t* lo8, hipStream_t s);
+                        uint8_t* lo8, hipStream_t s, char* ilv = nullptr);   // ilv (PREC_F16F8, f8_exp == kF8Act): interleaved lines instead of the planes
 int launch_attention_f16f8(awt_ctx* c, const F8Planes& q, const F8Planes& k, const F8Planes& v, const F8Planes& o, float* o_f32,
-                           float* lse, int B, int H, int S, hipStream_t s);
+                           float* lse, int B, int H, int S, hipStream_t s, char* o_ilv = nullptr);   // o_ilv: the output as interleaved lines (Act::ilv) instead of o
 // weights: dst(row_off + n, col_off + k) = scale * src[n, c, dt], k = dt * C + c (taps = 1: plain [N, C]); dst is a
 // fragment-major matrix with ld / 32 k-steps (ld = its K, a multiple of 32; its row count a multiple of 16)
 // prec PREC_F16F8: hi = fp16 plane (w16f8_index order), lo = the hi8 plane, lo8 = the lo8 plane (w8_index order); else hi / lo in

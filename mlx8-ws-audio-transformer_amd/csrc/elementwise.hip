@@ -1,5 +1,6 @@
 // HBM-bound row kernels of the encoder: LayerNorm (K8), fp32 -> split-bf16 planes, weight packing, conv1 im2col.
 #include "common.h"
+#include "gemm_pp.h"
 
 #ifndef AWT_LN_NT_LOAD
 #define AWT_LN_NT_LOAD 1   // -0.3 .. -0.4 ms per encoder step, most of it in the GEMM that follows (profiles/r03_gemm_experiments.txt)
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ x,
 
 template <int PREC>
 __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, int64_t n4, float scale, float f8_scale, bf16_t* p16,
-                                                           bf16_t* lo16, uint8_t* hi8, uint8_t* lo8) {
+                                                           bf16_t* lo16, uint8_t* hi8, uint8_t* lo8, char* ilv) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
     const float4 q = reinterpret_cast<const float4*>(x)[i];
     const float v[4] = {q.x * scale, q.y * scale, q.z * scale, q.w * scale};
@@ -86,9 +87,12 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
       float lo[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) { h[t] = f32_to_f16(v[t]); lo[t] = (v[t] - f16_to_f32(h[t])) * (f8_scale * pow2f(kF8Lo)); }
-      reinterpret_cast<uint2*>(p16)[i] = make_uint2(pack2(h[0], h[1]), pack2(h[2], h[3]));
-      reinterpret_cast<unsigned*>(hi8)[i] = fp8x4<0>(v[0] * f8_scale, v[1] * f8_scale, v[2] * f8_scale, v[3] * f8_scale);
-      reinterpret_cast<unsigned*>(lo8)[i] = fp8x4<0>(lo[0], lo[1], lo[2], lo[3]);
+      const uint2 h16 = make_uint2(pack2(h[0], h[1]), pack2(h[2], h[3]));
+      const unsigned b_hi = fp8x4<0>(v[0] * f8_scale, v[1] * f8_scale, v[2] * f8_scale, v[3] * f8_scale), b_lo = fp8x4<0>(lo[0], lo[1], lo[2], lo[3]);
+      if (ilv) { store_ilv4(ilv, i * 4, h16, b_hi, b_lo); continue; }
+      reinterpret_cast<uint2*>(p16)[i] = h16;
+      reinterpret_cast<unsigned*>(hi8)[i] = b_hi;
+      reinterpret_cast<unsigned*>(lo8)[i] = b_lo;
     } else {
 #pragma unroll
       for (int t = 0; t < 4; ++t) split16<PREC == PREC_F16X3>(v[t], h[t], l[t]);
@@ -130,6 +134,25 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
     }
   }
   if ((PREC == PREC_F16F8 || PREC == PREC_F16X3) && inexact && __builtin_amdgcn_ballot_w64(any_inexact) != 0 && (threadIdx.x & 63) == 0) atomicOr(inexact, 1);
+}
+
+// The packed weight image of the ping-pong GEMM (gemm_pp.h): per (256-column tile, 32-deep K-tile, half) one 16 KB region in LDS image order, each
+// row a 128-byte line fp16 x 32 | lo8 x 32 | hi8 x 32 with its 16-byte chunks XOR-swizzled by the row.  One thread per four consecutive k of a row.
+__global__ __launch_bounds__(256) void pack_weight_pp_kernel(const float* __restrict__ src, int N, int K, int row_off, char* dst) {
+  const int nk = K >> 5;
+  const int64_t total = (int64_t)N * (K >> 2);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i / (K >> 2)), k = (int)(i - (int64_t)n * (K >> 2)) * 4;
+    const float4 q = *reinterpret_cast<const float4*>(src + (int64_t)n * K + k);
+    const float v[4] = {q.x, q.y, q.z, q.w};
+    uint2 h16; unsigned hi8, lo8;
+    f16f8x4<kF8Wgt>(v, h16, hi8, lo8);
+    const int row = row_off + n, bn = row >> 8, nin = row & 255, sgrp = (nin >> 5) & 1, kt = k >> 5, g = (k & 31) >> 2;
+    char* reg = dst + pp::w_region_offset(bn, kt, sgrp, nk);
+    *reinterpret_cast<uint2*>(reg + pp::w_row_offset(nin, g >> 1) + (g & 1) * 8) = h16;
+    *reinterpret_cast<unsigned*>(reg + pp::w_row_offset(nin, 4 + (g >> 2)) + (g & 3) * 4) = lo8;
+    *reinterpret_cast<unsigned*>(reg + pp::w_row_offset(nin, 6 + (g >> 2)) + (g & 3) * 4) = hi8;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ conv1 im2col
@@ -426,8 +449,9 @@ __global__ __launch_bounds__(256) void planes_f6_kernel(const float* __restrict_
 
 int launch_layernorm(awt_ctx* c, const float* x, const float* gamma, const float* beta, int M, int d, float eps,
                      float* out_f32, const Act& out, int prec, hipStream_t s) {
-  AWT_REQUIRE(x && gamma && beta && (out_f32 || out.p16), AWT_ERR_INVALID, "layernorm: null argument");
-  AWT_REQUIRE(out_f32 || prec != PREC_F16F8 || out.lo8, AWT_ERR_INVALID, "layernorm: f16f8 output needs its lo8 plane (hi8 may be null: not consumed)");
+  AWT_REQUIRE(x && gamma && beta && (out_f32 || out.p16 || out.ilv), AWT_ERR_INVALID, "layernorm: null argument");
+  AWT_REQUIRE(out_f32 || prec != PREC_F16F8 || out.lo8 || out.ilv, AWT_ERR_INVALID, "layernorm: f16f8 output needs its lo8 plane (hi8 may be null: not consumed)");
+  AWT_REQUIRE(!out.ilv || out_f32 || (prec == PREC_F16F8 && d % 32 == 0), AWT_ERR_INVALID, "layernorm: interleaved lines are an f16f8 format of whole 32-element lines");
   AWT_REQUIRE(M > 0 && d > 0 && d % 4 == 0 && d <= 64 * 4 * kLnMaxChunks, AWT_ERR_INVALID, "layernorm: d must be a multiple of 4 and <= 1280");
   ProfScope prof(c, AWT_PROF_LAYERNORM, s, 0.0);
   const dim3 grid((M + 3) / 4), block(256);
@@ -449,18 +473,29 @@ int launch_split_f32(awt_ctx* c, const float* x, int64_t n, float scale, bf16_t*
 }
 
 int launch_split_planes(awt_ctx* c, const float* x, int64_t n, float scale, int prec, int f8_exp, bf16_t* p16, bf16_t* lo16, uint8_t* hi8,
-                        uint8_t* lo8, hipStream_t s) {
-  AWT_REQUIRE(x && p16 && n > 0 && n % 4 == 0, AWT_ERR_INVALID, "split: n must be a positive multiple of 4");
+                        uint8_t* lo8, hipStream_t s, char* ilv) {
+  AWT_REQUIRE(x && (p16 || ilv) && n > 0 && n % 4 == 0, AWT_ERR_INVALID, "split: n must be a positive multiple of 4");
   AWT_REQUIRE(prec == PREC_BF16 || prec == PREC_BF16X3 || prec == PREC_F16X3 || prec == PREC_F16F8, AWT_ERR_INVALID, "split: unknown precision");
-  AWT_REQUIRE(prec != PREC_F16F8 || (hi8 && lo8), AWT_ERR_INVALID, "split: f16f8 needs both e4m3 planes");
+  AWT_REQUIRE(prec != PREC_F16F8 || (hi8 && lo8) || ilv, AWT_ERR_INVALID, "split: f16f8 needs both e4m3 planes");
+  AWT_REQUIRE(!ilv || (prec == PREC_F16F8 && n % 32 == 0), AWT_ERR_INVALID, "split: interleaved lines are an f16f8 format of whole 32-element lines");
   AWT_REQUIRE(f8_exp >= -20 && f8_exp <= 20, AWT_ERR_INVALID, "split: bad e4m3 exponent");
   ProfScope prof(c, AWT_PROF_OTHER, s, 0.0);
   const int64_t n4 = n / 4;
   int grid = (int)((n4 + 255) / 256); if (grid > 4096) grid = 4096;
   const float f8s = f8_exp >= 0 ? (float)(1u << f8_exp) : 1.0f / (float)(1u << -f8_exp);
-  if (prec == PREC_F16F8) hipLaunchKernelGGL(split_planes_kernel<PREC_F16F8>, dim3(grid), dim3(256), 0, s, x, n4, scale, f8s, p16, lo16, hi8, lo8);
-  else if (prec == PREC_F16X3) hipLaunchKernelGGL(split_planes_kernel<PREC_F16X3>, dim3(grid), dim3(256), 0, s, x, n4, scale, f8s, p16, lo16, hi8, lo8);
-  else hipLaunchKernelGGL(split_planes_kernel<PREC_BF16X3>, dim3(grid), dim3(256), 0, s, x, n4, scale, f8s, p16, prec == PREC_BF16 ? nullptr : lo16, hi8, lo8);
+  if (prec == PREC_F16F8) hipLaunchKernelGGL(split_planes_kernel<PREC_F16F8>, dim3(grid), dim3(256), 0, s, x, n4, scale, f8s, p16, lo16, hi8, lo8, ilv);
+  else if (prec == PREC_F16X3) hipLaunchKernelGGL(split_planes_kernel<PREC_F16X3>, dim3(grid), dim3(256), 0, s, x, n4, scale, f8s, p16, lo16, hi8, lo8, nullptr);
+  else hipLaunchKernelGGL(split_planes_kernel<PREC_BF16X3>, dim3(grid), dim3(256), 0, s, x, n4, scale, f8s, p16, prec == PREC_BF16 ? nullptr : lo16, hi8, lo8, nullptr);
+  AWT_HIP_CHECK(hipGetLastError());
+  return AWT_OK;
+}
+
+size_t gemm_pp_weight_bytes(int N, int K) { return (size_t)((N + 255) / 256 * 256) * K * 4; }
+int launch_pack_weight_pp(awt_ctx* c, const float* src, int N, int K, int row_off, char* dst, hipStream_t s) {
+  AWT_REQUIRE(src && dst && N > 0 && K > 0 && K % 64 == 0 && row_off >= 0, AWT_ERR_INVALID, "pack_weight_pp: K must be a multiple of 64");
+  const int64_t total = (int64_t)N * (K / 4);
+  int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(pack_weight_pp_kernel, dim3(grid), dim3(256), 0, s, src, N, K, row_off, dst);
   AWT_HIP_CHECK(hipGetLastError());
   return AWT_OK;
 }

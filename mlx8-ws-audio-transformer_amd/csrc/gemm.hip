@@ -26,6 +26,7 @@
 #include <cstdlib>
 #include <type_traits>
 #include "common.h"
+#include "gemm_pp.h"
 
 #ifndef AWT_GEMM_GM
 #define AWT_GEMM_GM 8   // tools/gemm_gm_sweep.py: 6 - 8 row panels per group are ~1 % ahead of 4 and 16 on every encoder shape
@@ -252,7 +253,7 @@ __device__ __forceinline__ void store_out4(const GemmOut& o, int m, int n, float
 // FULL: the tile lies inside [0, M) x [0, n_valid) (decided once per workgroup): no per-row predicate, hence no branch between the stores of a strip --
 // with one, hipcc opened every row group with s_waitcnt vmcnt(0), i.e. waited for the previous group's stores to be acknowledged, 16 times per tile.
 // b0 / b1: the lane's eight bias values, loaded once per tile (its columns are the same in every strip).
-template <int EPI, bool FULL>
+template <int EPI, bool FULL, bool ILV = false>
 __device__ __forceinline__ void store_out8_f8(const GemmOut& o, int m, int n, float4 acc0, float4 acc1, float4 side0, float4 side1, float4 b0, float4 b1, int M) {
   // EPI_BF16_GELU_SAVE / EPI_BF16_DGELU: the MLP's forward / backward GEMMs of the training step with backward_terms = 5
   if constexpr (!FULL) { if (m >= M || n >= o.n_valid) return; }
@@ -312,6 +313,14 @@ __device__ __forceinline__ void store_out8_f8(const GemmOut& o, int m, int n, fl
 #ifdef AWT_DIAG_NO_STORE   // timing-only: every store instruction stays, but all waves write the same 1 KB per plane (L2-resident: no HBM write traffic)
   off = (threadIdx.x & 63) * 8;
 #endif
+  if constexpr (ILV) {   // interleaved lines (Act::ilv): the eight columns are a quarter q of one 128-byte line: fp16 bytes 16 q, hi8 64 + 8 q, lo8 96 + 8 q
+    char* line = o.ilv + (off >> 5) * 128;
+    const int q = (int)(off & 31) >> 3;
+    __builtin_nontemporal_store((i32x4_t){(int)pack2(h[0], h[1]), (int)pack2(h[2], h[3]), (int)pack2(h[4], h[5]), (int)pack2(h[6], h[7])}, reinterpret_cast<i32x4_t*>(line + q * 16));
+    __builtin_nontemporal_store((i32x2){(int)fp8x4_rt(v[0], v[1], v[2], v[3], lim8, inv8), (int)fp8x4_rt(v[4], v[5], v[6], v[7], lim8, inv8)}, reinterpret_cast<i32x2*>(line + 64 + q * 8));
+    __builtin_nontemporal_store((i32x2){(int)fp8x4_rt(l[0], l[1], l[2], l[3], liml8, invl8), (int)fp8x4_rt(l[4], l[5], l[6], l[7], liml8, invl8)}, reinterpret_cast<i32x2*>(line + 96 + q * 8));
+    return;
+  }
 #if AWT_GEMM_NT_STORE   // the planes are read next by another kernel, not by this one -> streaming stores (profiles/r03_gemm_experiments.txt)
   __builtin_nontemporal_store((i32x4_t){(int)pack2(h[0], h[1]), (int)pack2(h[2], h[3]), (int)pack2(h[4], h[5]), (int)pack2(h[6], h[7])}, reinterpret_cast<i32x4_t*>(o.hi + off));
   if (EPI == EPI_QKV && o.skip_v8 && n >= 2 * o.H * 64) return;
@@ -955,6 +964,76 @@ int launch_f8(GemmArgs a, hipStream_t s) {
 }
 
 
+
+// ================================================================================================ persistent ping-pong kernel (gemm_pp.h)
+// 256 x 256 tiles, 8 waves, one workgroup per CU walking its tiles with one continuous K-tile stream; PREC_F16F8, one plain K segment.
+// The epilogue is the one above (per-wave LDS transposition of 32 x 64 strips, eight columns per lane, whole row segments per store),
+// with the patch in the wave's 8 KB of the last 64 KB of LDS (pitch 64 floats, 16-byte groups XOR-ed by the row's parity against
+// bank conflicts on the transposed read) and its stores left in flight while the next tile's K loop starts.
+template <int EPI, bool ILV>
+__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(pp::Args g, GemmOut out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 2, wc = wave & 3, r32 = lane & 31, half = lane >> 5;
+  float* patch = reinterpret_cast<float*>(smem + pp::PATCH_BASE + wave * 8192);
+  const int c8 = (lane & 7) * 8, r8 = lane >> 3;
+  constexpr bool SIDE = EPI == EPI_F32_RESID;
+  pp::kloop<pp::FMT_F16F8>(g, smem, [&](int tm, int tn, pp::Acc<pp::FMT_F16F8>& accs) {
+    auto& acc = accs.t;
+    const int m0 = tm * pp::BM, n0 = tn * pp::BN;
+    const int em0 = m0 + wr * 128, en = n0 + wc * 64 + c8;
+    float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+    if (out.bias && en < out.n_valid) { b0 = *reinterpret_cast<const float4*>(out.bias + en); b1 = *reinterpret_cast<const float4*>(out.bias + en + 4); }
+    auto strips = [&](auto full_t) {
+      constexpr bool FULL = decltype(full_t)::value;
+      float4 side[4][2], side_next[4][2];
+      auto load_sides = [&](float4 (&d)[4][2], int i) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          d[it][0] = load_side4<EPI, FULL>(out, em0 + i * 32 + r8 + 8 * it, en, g.M);
+          d[it][1] = load_side4<EPI, FULL>(out, em0 + i * 32 + r8 + 8 * it, en + 4, g.M);
+        }
+      };
+      if constexpr (SIDE) load_sides(side, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int rr = 0; rr < 16; ++rr) {
+            const int row = (rr & 3) + 8 * (rr >> 2) + 4 * half;
+            patch[row * 64 + ((j * 32 + r32) ^ ((row & 1) << 2))] = acc[i][j][rr];
+          }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (SIDE) { if (i + 1 < 4) load_sides(side_next, i + 1); }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int rl = r8 + 8 * it, sw = (rl & 1) << 2;
+          const float4 v0 = *reinterpret_cast<const float4*>(patch + rl * 64 + (c8 ^ sw)), v1 = *reinterpret_cast<const float4*>(patch + rl * 64 + ((c8 + 4) ^ sw));
+          store_out8_f8<EPI, FULL, ILV>(out, em0 + i * 32 + rl, en, v0, v1, side[it][0], side[it][1], b0, b1, g.M);
+        }
+        if constexpr (SIDE) {
+#pragma unroll
+          for (int it = 0; it < 4; ++it) { side[it][0] = side_next[it][0]; side[it][1] = side_next[it][1]; }
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+    };
+    if (m0 + pp::BM <= g.M && n0 + pp::BN <= out.n_valid) strips(std::true_type{}); else strips(std::false_type{});
+  });
+}
+
+template <int EPI, bool ILV>
+int launch_pp(const pp::Args& a, const GemmOut& o, int grid, hipStream_t s) {
+  AWT_ONCE_PER_DEVICE(AWT_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI, ILV>, hipFuncAttributeMaxDynamicSharedMemorySize, pp::LDS_BYTES)));
+  hipLaunchKernelGGL((gemm_pp_kernel<EPI, ILV>), dim3(grid), dim3(pp::NT), pp::LDS_BYTES, s, a, o);
+  AWT_HIP_CHECK(hipGetLastError());
+  return AWT_OK;
+}
+
 #ifdef AWT_EXPERIMENTAL_F6   // round-2 experiment: not compiled into the shipped library
 // ================================================================================================ PREC_F16F6 (experimental)
 // The f16f8 kernel with the two correction planes in FP6 e3m2: per fragment pair the fp16 product (4 x 32 pipe cycles per 64-deep K-tile and
@@ -1323,6 +1402,41 @@ int launch_gemm_batched(awt_ctx* c, int batch, int M, int N, int K, const bf16_t
   a.bs_a = bs_a; a.bs_w = bs_w; a.bs_o = bs_o;
   ProfScope prof(c, AWT_PROF_GEMM, s, 2.0 * (double)batch * (double)M * (double)n_valid * (double)K);
   return resid ? launch_batched_epi<EPI_F32_RESID>(a, batch, s) : launch_batched_epi<EPI_F32>(a, batch, s);
+}
+
+// tuning knob "gemm_pp": 0 = off (default), 1 = automatic (large launches on weights that are not fp16-exact), 2 = wherever supported.
+// Measured on the headline step (profiles/r04_gemm_pp_encoder_ab.txt, interleaved A/B in one process): GEMM class 33.83 (shipped) vs 33.75 ms (mode 1),
+// LayerNorm + 0.57 ms (its interleaved-line stores): a tie, so the shipped two-workgroups-per-CU kernels stay the default.
+int g_pp_mode = 0;
+int awt_gemm_pp_mode() { return g_pp_mode; }
+void awt_gemm_set_pp_mode(int v) { g_pp_mode = v; }
+bool gemm_pp_supported(int M, int N, int K, int epi) {
+  return M > 0 && N > 0 && N % 256 == 0 && K >= 128 && K % 64 == 0 &&
+         (epi == EPI_F32 || epi == EPI_F32_RESID || epi == EPI_BF16 || epi == EPI_BF16_GELU || epi == EPI_QKV);
+}
+int launch_gemm_pp(awt_ctx* c, int M, int N, const GemmSeg& seg, GemmEpilogue epi, const GemmOut& out, hipStream_t s) {
+  AWT_REQUIRE(c && gemm_pp_supported(M, N, seg.K, epi), AWT_ERR_INVALID, "gemm (ping-pong): N % 256 == 0, K % 64 == 0, K >= 128 and a supported epilogue required");
+  AWT_REQUIRE(seg.a_ilv && seg.w_pp && seg.rows_out == M && seg.rows_in == M && seg.row_mul == 1 && seg.row_add == 0 && seg.w_k0 == 0 && seg.w_ksteps == seg.K / 32 && seg.lda == seg.K,
+              AWT_ERR_INVALID, "gemm (ping-pong): one plain, dense K segment over interleaved-line activations and a packed weight image");
+  AWT_REQUIRE(!out.ilv || ((epi == EPI_BF16 || epi == EPI_BF16_GELU) && out.ldo == N && out.n_valid == N), AWT_ERR_INVALID, "gemm (ping-pong): an interleaved-line output is a dense [M, N] activation");
+  pp::Args a{};
+  a.A = seg.a_ilv; a.a_row_bytes = (int64_t)seg.lda * 4; a.W = seg.w_pp;
+  a.M = M; a.N = N; a.K = seg.K; a.nk = seg.K / 32;
+  a.tiles_m = (M + pp::BM - 1) / pp::BM; a.tiles_n = N / pp::BN; a.ntiles = a.tiles_m * a.tiles_n; a.gm = g_gm;
+  static int n_cu[64] = {};
+  int dev = 0; AWT_HIP_CHECK(hipGetDevice(&dev));
+  if (!n_cu[dev & 63]) { hipDeviceProp_t p; AWT_HIP_CHECK(hipGetDeviceProperties(&p, dev)); n_cu[dev & 63] = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256; }
+  const int grid = std::min(a.ntiles, n_cu[dev & 63]);          // one persistent workgroup per CU (all of its LDS)
+  ProfScope prof(c, AWT_PROF_GEMM, s, 2.0 * (double)M * (double)out.n_valid * (double)seg.K);
+  switch (epi) {
+    case EPI_F32: return launch_pp<EPI_F32, false>(a, out, grid, s);
+    case EPI_F32_RESID: return launch_pp<EPI_F32_RESID, false>(a, out, grid, s);
+    case EPI_BF16: return out.ilv ? launch_pp<EPI_BF16, true>(a, out, grid, s) : launch_pp<EPI_BF16, false>(a, out, grid, s);
+    case EPI_BF16_GELU: return out.ilv ? launch_pp<EPI_BF16_GELU, true>(a, out, grid, s) : launch_pp<EPI_BF16_GELU, false>(a, out, grid, s);
+    case EPI_QKV: return launch_pp<EPI_QKV, false>(a, out, grid, s);
+    default: break;
+  }
+  return awt_fail(AWT_ERR_INVALID, "gemm (ping-pong): unsupported epilogue");
 }
 
 void awt_gemm_force_tile(int t) { g_force_tile = t; }

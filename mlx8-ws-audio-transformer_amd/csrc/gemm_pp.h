@@ -59,6 +59,9 @@ struct Args {
   const char* W;          // packed regions (above), N padded to a multiple of 256
   int M, N, K, nk;        // nk = K-tiles per output tile (even)
   int tiles_m, tiles_n, ntiles, gm;
+  // start-up stagger: workgroup group g = (blockIdx.x / 8) % 4 starts g * nk * stagger * 128 cycles late (stagger = 4: a quarter of a tile's K loop per
+  // group), so that the workgroups of an XCD reach their epilogues -- the output bursts -- at different times instead of all at once; 0 = off
+  int stagger;
 };
 
 template <int OFF>
@@ -115,6 +118,10 @@ __device__ __forceinline__ void kloop(const Args& g, char* smem, EPI&& epi) {
   const int nk = g.nk;
   const int nmine = (g.ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
   if (nmine <= 0) return;
+  if (g.stagger > 0) {
+    const int n = (int)((blockIdx.x >> 3) & 3) * nk * g.stagger;
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(2);
+  }
 
   // tile order: XCD-contiguous runs, groups of GM row panels (as gemm.hip)
   auto tile_coords = [&](int it, int& tm, int& tn) {

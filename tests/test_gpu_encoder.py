@@ -72,6 +72,31 @@ def test_encoder_other_parity_modes_vs_oracle(precision, name, trimmed, batch):
     assert e["max_abs"] < (2e-4 if precision == "fp16x3" else 5e-4), e      # fp32 oracle noise ~1e-5..1e-4 at these sizes
 
 
+# the same mode with the four linears of every layer on the persistent ping-pong GEMM ("gemm_pp" = 2: also at these small batches, where the
+# automatic choice keeps the 128-row tiles): interleaved-line activations from LayerNorm / the attention epilogue / fc1's GELU epilogue
+@pytest.mark.parametrize("name,trimmed,batch", [("small", True, 2), ("small", False, 2), ("base", False, 1), ("tiny", True, 2)])
+def test_encoder_f16f8_on_the_ping_pong_gemm(name, trimmed, batch):
+    from mlx8_ws_audio_transformer_amd import _lib
+    cfg = wts.config(name, trimmed)
+    W = wts.init_encoder_weights(cfg, 0, "test")
+    mel = _mel(cfg, batch)
+    enc = _native(cfg, "f16f8")
+    x = torch.from_numpy(mel).cuda()
+    base = enc(x).last_hidden_state.cpu().numpy()
+    _lib.tuning_set("gemm_pp", 2)
+    try:
+        out = enc(x).last_hidden_state.cpu().numpy()
+    finally:
+        _lib.tuning_set("gemm_pp", 0)
+    ref = oracle_enc.encoder_forward(W, mel, cfg.heads).numpy()
+    e = oracle_enc.error_norms(out, ref)
+    print(name, trimmed, e, "vs the shipped tiling", float(np.abs(out - base).max()))
+    assert e["max_abs"] < 5e-4, e
+    G = golden("encoder.npz")
+    if f"{cfg.name}/last_full" in G:
+        np.testing.assert_allclose(out, G[f"{cfg.name}/last_full"], rtol=0, atol=PARITY_TOL)
+
+
 def test_chunking_is_invisible():
     cfg = wts.config("tiny", True)
     mel = torch.from_numpy(_mel(cfg, 5)).cuda()

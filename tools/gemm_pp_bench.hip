@@ -127,13 +127,14 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_test(pp::Args g, TestOut o) {
 
 struct Problem { const char* name; int M, N, K; };
 
+static int g_stagger = 0;
 template <int FMT, int EPI>
 static float run(const Problem& p, char* A, char* W, float* C, int reps, int grid_limit = 256, unsigned long long* stamps = nullptr) {
   constexpr int KT = pp::ktile_elems(FMT);
   pp::Args g{};
   g.A = A; g.a_row_bytes = (long long)p.K * pp::elem_bytes(FMT); g.W = W;
   g.M = p.M; g.N = p.N; g.K = p.K; g.nk = p.K / KT;
-  g.tiles_m = (p.M + 255) / 256; g.tiles_n = (p.N + 255) / 256; g.ntiles = g.tiles_m * g.tiles_n; g.gm = 8;
+  g.tiles_m = (p.M + 255) / 256; g.tiles_n = (p.N + 255) / 256; g.ntiles = g.tiles_m * g.tiles_n; g.gm = 8; g.stagger = g_stagger;
   TestOut o{C, p.N, nullptr, p.M, p.N, stamps};
   const int grid = g.ntiles < grid_limit ? g.ntiles : grid_limit;
   static bool attr_set = false;
@@ -288,6 +289,20 @@ int main(int argc, char** argv) {
     for (const auto& p : shapes) timing<pp::FMT_F16F8>(p, 10);
     const Problem cube = {"4k", 4096, 4096, 4096}, cube8 = {"8k", 8192, 8192, 8192};
     timing<pp::FMT_F16>(cube, 10); timing<pp::FMT_F16_16>(cube, 10); timing<pp::FMT_F16>(cube8, 5); timing<pp::FMT_F16_16>(cube8, 5);
+  }
+  if (mode == "stagger") {
+    const Problem shapes[] = {{"qkv", M, 2304, 768}, {"out", M, 768, 768}, {"fc1", M, 3072, 768}, {"fc2", M, 768, 3072}};
+    for (const auto& p : shapes) {
+      char *A, *W; float* C;
+      prepare<pp::FMT_F16F8>(p, A, W, 99);
+      CK(hipMalloc(&C, (size_t)p.M * p.N * 4));
+      printf("stagger %-5s fp32-store epilogue, ms:", p.name);
+      for (int rep = 0; rep < 2; ++rep)
+        for (int st : {0, 1, 2, 3, 4, 6, 8}) { g_stagger = st; printf("  s%d %.3f", st, run<pp::FMT_F16F8, 1>(p, A, W, C, 8)); }
+      g_stagger = 0;
+      printf("\n"); fflush(stdout);
+      CK(hipFree(A)); CK(hipFree(W)); CK(hipFree(C));
+    }
   }
   if (mode == "ab" || mode == "all") {
     Awt L;
