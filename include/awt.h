@@ -110,6 +110,8 @@ typedef struct awt_encoder_cfg {
   int32_t n_ctx;            /* S = max_source_positions: 1500 (reference) or 200 (trimmed); mel T = 2*S    */
   int32_t mfma_terms;       /* operand precision of the forward pass:
                                1 bf16: one bf16 MFMA per fragment pair (fast; ~4e-3 rel-L2 vs fp32, misses the 1e-3 bound);
+                               2 fp16: one fp16 MFMA per fragment pair (11 significant bits per operand: max-abs ~2.5e-3 on
+                                 Whisper-small, misses the bound as well; a measurement mode, inference only);
                                3 bf16x3: split-bf16 hi + lo planes, three MFMAs (2^-17 per operand; the training format);
                                4 fp16x3: split-fp16 planes, three MFMAs (2^-23 per operand; operands within fp16's range);
                                5 f16f8: fp16 plane + two e4m3 planes, the two cross terms on the block-scaled fp8 MFMA: two
@@ -207,6 +209,10 @@ void awt_comm_destroy(awt_comm* m);
 int awt_comm_world(const awt_comm* m);
 int awt_allreduce_sum_f32(awt_comm* m, float* buf, size_t n, void* stream);
 int awt_allreduce_mean_f32(awt_comm* m, float* buf, size_t n, void* stream);
+/* Timing of the bucket reductions that awt_encoder_backward_ex issues on the communicator's side stream (AWT_BWD_ALLREDUCE): enable != 0 records a HIP
+ * event pair around each one from now on (at most 8 between read-outs); the call returns, and clears, what was recorded since the previous call --
+ * milliseconds on the side stream and bytes per bucket, in issue order -- so that a multi-GPU run can show that, and how long, the exchange ran. */
+int awt_comm_bucket_stats(awt_comm* m, int enable, double* ms, int64_t* bytes, int max, int* n_out);
 /* Attach a communicator to an encoder for AWT_BWD_ALLREDUCE; `groups` >= 1 layer groups (2 = upper / lower half;
  * clamped to the layer count).  m = NULL detaches. */
 int awt_encoder_set_comm(awt_encoder* e, awt_comm* m, int groups);

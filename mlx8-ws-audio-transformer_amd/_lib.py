@@ -31,7 +31,7 @@ class EncoderCfg(C.Structure):
                 ("lora_alpha", C.c_float), ("lora_targets", C.c_uint32), ("chunk_clips", C.c_int32), ("training", C.c_int32), ("backward_terms", C.c_int32)]
 
 
-MFMA_PER_PAIR = {"bf16": 1, "bf16x3": 3, "fp16x3": 3, "f16f8": 2}   # MFMA-equivalents issued per fragment pair, by precision mode
+MFMA_PER_PAIR = {"bf16": 1, "fp16": 1, "bf16x3": 3, "fp16x3": 3, "f16f8": 2}   # MFMA-equivalents issued per fragment pair, by precision mode
 BWD_ACCUMULATE, BWD_ALLREDUCE = 1, 2
 COMM_ID_BYTES = 128
 LORA_BITS = {"q_proj": 1, "k_proj": 2, "v_proj": 4, "out_proj": 8, "fc1": 16, "fc2": 32}
@@ -68,6 +68,7 @@ _SIGNATURES = {
     "awt_comm_world": (_i, [_vp]),
     "awt_allreduce_sum_f32": (_i, [_vp, _vp, _sz, _vp]),
     "awt_allreduce_mean_f32": (_i, [_vp, _vp, _sz, _vp]),
+    "awt_comm_bucket_stats": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_int64), _i, C.POINTER(_i)]),
     "awt_encoder_set_comm": (_i, [_vp, _vp, _i]),
     "awt_audio_encode_workspace_bytes": (_sz, [_vp, _i]),
     "awt_audio_encode": (_i, [_vp, _vp, _i, _i64, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),

@@ -313,7 +313,7 @@ int launch_attention(awt_ctx* c, const bf16_t* q_hi, const bf16_t* q_lo, const b
                      const bf16_t* v_hi, const bf16_t* v_lo, bf16_t* o_hi, bf16_t* o_lo, float* o_f32, float* lse, int B, int H,
                      int S, int prec, hipStream_t s) {
   AWT_REQUIRE(B > 0 && H > 0 && S > 0, AWT_ERR_INVALID, "attention: bad shape");
-  AWT_REQUIRE(prec == PREC_BF16 || prec == PREC_BF16X3 || prec == PREC_F16X3, AWT_ERR_INVALID, "attention: precision must be bf16 (1), bf16x3 (3) or fp16x3 (4) here");
+  AWT_REQUIRE(prec == PREC_BF16 || prec == PREC_F16 || prec == PREC_BF16X3 || prec == PREC_F16X3, AWT_ERR_INVALID, "attention: precision must be bf16 (1), fp16 (2), bf16x3 (3) or fp16x3 (4) here");
   const int terms = prec_products(prec);
   AWT_REQUIRE(q_hi && k_hi && v_hi && (o_hi || o_f32), AWT_ERR_INVALID, "attention: null plane");
   AWT_REQUIRE(terms == 1 || (q_lo && k_lo && v_lo), AWT_ERR_INVALID, "attention: lo planes required for terms == 3");
@@ -325,6 +325,7 @@ int launch_attention(awt_ctx* c, const bf16_t* q_hi, const bf16_t* q_lo, const b
   const int64_t wg2 = (int64_t)((S + 255) / 256) * B * H, wg1 = (int64_t)((S + 127) / 128) * B * H;
   const double cost2 = (double)((wg2 + 511) / 512), cost1 = 0.55 * (double)((wg1 + 511) / 512);
   if (prec == PREC_F16X3) return cost1 < cost2 ? launch_t<3, 1, true>(a, s) : launch_t<3, 2, true>(a, s);
+  if (prec == PREC_F16) return cost1 < cost2 ? launch_t<1, 1, true>(a, s) : launch_t<1, 2, true>(a, s);
   if (cost1 < cost2) return terms == 3 ? launch_t<3, 1>(a, s) : launch_t<1, 1>(a, s);
   return terms == 3 ? launch_t<3, 2>(a, s) : launch_t<1, 2>(a, s);
 }

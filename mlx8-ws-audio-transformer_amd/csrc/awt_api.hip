@@ -556,8 +556,8 @@ extern "C" int awt_encoder_create(awt_ctx* c, const awt_encoder_cfg* cfg, awt_en
   AWT_REQUIRE(cfg->ffn_dim > 0 && cfg->ffn_dim % 128 == 0, AWT_ERR_INVALID, "encoder_create: ffn_dim must be a multiple of 128");
   AWT_REQUIRE(cfg->n_mels > 0 && cfg->n_mels % 8 == 0 && cfg->n_mels <= 128, AWT_ERR_INVALID, "encoder_create: n_mels must be a multiple of 8, <= 128");
   AWT_REQUIRE(cfg->n_layers > 0 && cfg->n_ctx > 0, AWT_ERR_INVALID, "encoder_create: n_layers and n_ctx must be positive");
-  AWT_REQUIRE(cfg->mfma_terms == PREC_BF16 || cfg->mfma_terms == PREC_BF16X3 || cfg->mfma_terms == PREC_F16X3 || cfg->mfma_terms == PREC_F16F8, AWT_ERR_INVALID,
-              "encoder_create: mfma_terms must be 1 (bf16), 3 (bf16x3), 4 (fp16x3) or 5 (f16f8)");
+  AWT_REQUIRE(cfg->mfma_terms == PREC_BF16 || cfg->mfma_terms == PREC_F16 || cfg->mfma_terms == PREC_BF16X3 || cfg->mfma_terms == PREC_F16X3 || cfg->mfma_terms == PREC_F16F8, AWT_ERR_INVALID,
+              "encoder_create: mfma_terms must be 1 (bf16), 2 (fp16), 3 (bf16x3), 4 (fp16x3) or 5 (f16f8)");
   AWT_REQUIRE(!cfg->training || cfg->mfma_terms == PREC_BF16 || cfg->mfma_terms == PREC_BF16X3, AWT_ERR_INVALID,
               "encoder_create: training keeps its activations as bf16 planes: mfma_terms must be 1 or 3 (gradients do not fit fp16's range unscaled)");
   AWT_REQUIRE(cfg->backward_terms == 0 || cfg->backward_terms == cfg->mfma_terms || ((cfg->backward_terms == 1 || cfg->backward_terms == PREC_F16F8) && cfg->mfma_terms == 3),
@@ -568,7 +568,7 @@ extern "C" int awt_encoder_create(awt_ctx* c, const awt_encoder_cfg* cfg, awt_en
   AWT_REQUIRE(cfg->lora_rank == 0 || cfg->lora_targets != 0, AWT_ERR_INVALID, "encoder_create: lora_rank > 0 needs lora_targets");
   AWT_REQUIRE(!cfg->training || cfg->lora_rank > 0, AWT_ERR_INVALID, "encoder_create: training mode needs adapters (lora_rank > 0)");
   awt_encoder* e = new awt_encoder();
-  e->ctx = c; e->cfg = *cfg; e->prec = cfg->mfma_terms; e->planes = cfg->mfma_terms == PREC_BF16 ? 1 : 2;
+  e->ctx = c; e->cfg = *cfg; e->prec = cfg->mfma_terms; e->planes = (cfg->mfma_terms == PREC_BF16 || cfg->mfma_terms == PREC_F16) ? 1 : 2;
   e->chunk = cfg->chunk_clips > 0 ? cfg->chunk_clips : 64;
   e->mlp_f8 = cfg->backward_terms == PREC_F16F8;
   const int d = cfg->d_model, f = cfg->ffn_dim;

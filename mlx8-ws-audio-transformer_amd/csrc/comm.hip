@@ -104,6 +104,7 @@ extern "C" void awt_comm_destroy(awt_comm* m) {
   if (!m) return;
   if (m->side) { (void)hipStreamSynchronize(m->side); (void)hipStreamDestroy(m->side); }
   for (hipEvent_t ev : m->ev) if (ev) (void)hipEventDestroy(ev);
+  for (awt_comm::Span& sp : m->spans) { if (sp.a) (void)hipEventDestroy(sp.a); if (sp.b) (void)hipEventDestroy(sp.b); }
   if (m->nccl && rccl()) rccl()->comm_destroy(m->nccl);
   delete m;
 }
@@ -123,7 +124,31 @@ int comm_reduce_async(awt_comm* m, float* buf, size_t n, hipStream_t producer) {
   m->next_ev = (m->next_ev + 1) % (int)(sizeof(m->ev) / sizeof(m->ev[0]) - 1);
   AWT_HIP_CHECK(hipEventRecord(ev, producer));
   AWT_HIP_CHECK(hipStreamWaitEvent(m->side, ev, 0));
-  return reduce(m, buf, n, kNcclAvg, m->side, "allreduce_mean_f32 (side stream)");
+  awt_comm::Span* sp = (m->timing && m->n_spans < (int)(sizeof(m->spans) / sizeof(m->spans[0]))) ? &m->spans[m->n_spans] : nullptr;
+  if (sp) {
+    if (!sp->a) { AWT_HIP_CHECK(hipEventCreate(&sp->a)); AWT_HIP_CHECK(hipEventCreate(&sp->b)); }
+    AWT_HIP_CHECK(hipEventRecord(sp->a, m->side));
+  }
+  const int rc = reduce(m, buf, n, kNcclAvg, m->side, "allreduce_mean_f32 (side stream)");
+  if (sp && !rc) { AWT_HIP_CHECK(hipEventRecord(sp->b, m->side)); sp->bytes = n * 4; ++m->n_spans; }
+  return rc;
+}
+
+// Bucket timing of the in-backward exchange: enable != 0 starts recording an event pair around every side-stream reduction (at most 8 per read-out);
+// the call returns, and clears, what was recorded since the previous call: milliseconds on the side stream and bytes per bucket, in issue order.
+extern "C" int awt_comm_bucket_stats(awt_comm* m, int enable, double* ms, int64_t* bytes, int max, int* n_out) {
+  AWT_REQUIRE(m && n_out, AWT_ERR_INVALID, "comm_bucket_stats: null argument");
+  int n = 0;
+  for (int i = 0; i < m->n_spans; ++i) {
+    AWT_HIP_CHECK(hipEventSynchronize(m->spans[i].b));
+    float t = 0.f;
+    AWT_HIP_CHECK(hipEventElapsedTime(&t, m->spans[i].a, m->spans[i].b));
+    if (ms && bytes && n < max) { ms[n] = t; bytes[n] = (int64_t)m->spans[i].bytes; ++n; }
+  }
+  m->n_spans = 0;
+  m->timing = enable != 0;
+  *n_out = n;
+  return AWT_OK;
 }
 // everything enqueued on `consumer` after this call sees the side stream's completed reductions
 int comm_join(awt_comm* m, hipStream_t consumer) {

@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
       reinterpret_cast<uint2*>(dx_hi + (int64_t)row * d)[c] = make_uint2(pack2(hi[0], hi[1]), pack2(hi[2], hi[3]));
       if (dx_lo) reinterpret_cast<uint2*>(dx_lo + (int64_t)row * d)[c] = make_uint2(pack2(lo[0], lo[1]), pack2(lo[2], lo[3]));
     }
-    if (out8.p16) store_act4<PREC_F16F8>(out8, (int64_t)row * d + 4 * c, y);
+    if (out8.p16) store_act4<PREC_F16F8, kF8Act, true>(out8, (int64_t)row * d + 4 * c, y);   // gradient planes saturate instead of overflowing (common.h f16f8x4)
   }
 }
 
@@ -456,7 +456,7 @@ int launch_layernorm(awt_ctx* c, const float* x, const float* gamma, const float
   ProfScope prof(c, AWT_PROF_LAYERNORM, s, 0.0);
   const dim3 grid((M + 3) / 4), block(256);
   if (prec == PREC_F16F8) hipLaunchKernelGGL(layernorm_kernel<PREC_F16F8>, grid, block, 0, s, x, gamma, beta, M, d, eps, out_f32, out);
-  else if (prec == PREC_F16X3) hipLaunchKernelGGL(layernorm_kernel<PREC_F16X3>, grid, block, 0, s, x, gamma, beta, M, d, eps, out_f32, out);
+  else if (prec == PREC_F16X3 || prec == PREC_F16) hipLaunchKernelGGL(layernorm_kernel<PREC_F16X3>, grid, block, 0, s, x, gamma, beta, M, d, eps, out_f32, out);   // PREC_F16: lo16 is null
   else hipLaunchKernelGGL(layernorm_kernel<PREC_BF16X3>, grid, block, 0, s, x, gamma, beta, M, d, eps, out_f32, out);
   AWT_HIP_CHECK(hipGetLastError());
   return AWT_OK;
@@ -475,7 +475,7 @@ int launch_split_f32(awt_ctx* c, const float* x, int64_t n, float scale, bf16_t*
 int launch_split_planes(awt_ctx* c, const float* x, int64_t n, float scale, int prec, int f8_exp, bf16_t* p16, bf16_t* lo16, uint8_t* hi8,
                         uint8_t* lo8, hipStream_t s, char* ilv) {
   AWT_REQUIRE(x && (p16 || ilv) && n > 0 && n % 4 == 0, AWT_ERR_INVALID, "split: n must be a positive multiple of 4");
-  AWT_REQUIRE(prec == PREC_BF16 || prec == PREC_BF16X3 || prec == PREC_F16X3 || prec == PREC_F16F8, AWT_ERR_INVALID, "split: unknown precision");
+  AWT_REQUIRE(prec == PREC_BF16 || prec == PREC_F16 || prec == PREC_BF16X3 || prec == PREC_F16X3 || prec == PREC_F16F8, AWT_ERR_INVALID, "split: unknown precision");
   AWT_REQUIRE(prec != PREC_F16F8 || (hi8 && lo8) || ilv, AWT_ERR_INVALID, "split: f16f8 needs both e4m3 planes");
   AWT_REQUIRE(!ilv || (prec == PREC_F16F8 && n % 32 == 0), AWT_ERR_INVALID, "split: interleaved lines are an f16f8 format of whole 32-element lines");
   AWT_REQUIRE(f8_exp >= -20 && f8_exp <= 20, AWT_ERR_INVALID, "split: bad e4m3 exponent");
@@ -484,7 +484,7 @@ int launch_split_planes(awt_ctx* c, const float* x, int64_t n, float scale, int 
   int grid = (int)((n4 + 255) / 256); if (grid > 4096) grid = 4096;
   const float f8s = f8_exp >= 0 ? (float)(1u << f8_exp) : 1.0f / (float)(1u << -f8_exp);
   if (prec == PREC_F16F8) hipLaunchKernelGGL(split_planes_kernel<PREC_F16F8>, dim3(grid), dim3(256), 0, s, x, n4, scale, f8s, p16, lo16, hi8, lo8, ilv);
-  else if (prec == PREC_F16X3) hipLaunchKernelGGL(split_planes_kernel<PREC_F16X3>, dim3(grid), dim3(256), 0, s, x, n4, scale, f8s, p16, lo16, hi8, lo8, nullptr);
+  else if (prec == PREC_F16X3 || prec == PREC_F16) hipLaunchKernelGGL(split_planes_kernel<PREC_F16X3>, dim3(grid), dim3(256), 0, s, x, n4, scale, f8s, p16, prec == PREC_F16 ? nullptr : lo16, hi8, lo8, nullptr);
   else hipLaunchKernelGGL(split_planes_kernel<PREC_BF16X3>, dim3(grid), dim3(256), 0, s, x, n4, scale, f8s, p16, prec == PREC_BF16 ? nullptr : lo16, hi8, lo8, nullptr);
   AWT_HIP_CHECK(hipGetLastError());
   return AWT_OK;
@@ -507,7 +507,7 @@ int launch_pack_weight(awt_ctx* c, const float* src, int N, int C, int taps, int
   const int64_t total = (int64_t)N * C * taps;
   int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
   if (prec == PREC_F16F8) hipLaunchKernelGGL(pack_weight_kernel<PREC_F16F8>, dim3(grid), dim3(256), 0, s, src, N, C, taps, ld, row_off, col_off, scale, hi, lo, lo8, inexact);
-  else if (prec == PREC_F16X3) hipLaunchKernelGGL(pack_weight_kernel<PREC_F16X3>, dim3(grid), dim3(256), 0, s, src, N, C, taps, ld, row_off, col_off, scale, hi, lo, lo8, inexact);
+  else if (prec == PREC_F16X3 || prec == PREC_F16) hipLaunchKernelGGL(pack_weight_kernel<PREC_F16X3>, dim3(grid), dim3(256), 0, s, src, N, C, taps, ld, row_off, col_off, scale, hi, prec == PREC_F16 ? nullptr : lo, lo8, inexact);
   else hipLaunchKernelGGL(pack_weight_kernel<PREC_BF16X3>, dim3(grid), dim3(256), 0, s, src, N, C, taps, ld, row_off, col_off, scale, hi, lo, lo8, inexact);
   AWT_HIP_CHECK(hipGetLastError());
   return AWT_OK;
@@ -520,7 +520,7 @@ int launch_im2col_conv1(awt_ctx* c, const float* mel, int B, int C, int T, int K
   const size_t lds = (size_t)C * (kImTile + 3) * sizeof(float);
   const dim3 grid((T + kImTile - 1) / kImTile, B), block(256);
   if (prec == PREC_F16F8) hipLaunchKernelGGL(im2col_conv1_kernel<PREC_F16F8>, grid, block, lds, s, mel, C, T, K_dst, out);
-  else if (prec == PREC_F16X3) hipLaunchKernelGGL(im2col_conv1_kernel<PREC_F16X3>, grid, block, lds, s, mel, C, T, K_dst, out);
+  else if (prec == PREC_F16X3 || prec == PREC_F16) hipLaunchKernelGGL(im2col_conv1_kernel<PREC_F16X3>, grid, block, lds, s, mel, C, T, K_dst, out);
   else hipLaunchKernelGGL(im2col_conv1_kernel<PREC_BF16X3>, grid, block, lds, s, mel, C, T, K_dst, out);
   AWT_HIP_CHECK(hipGetLastError());
   return AWT_OK;

@@ -300,6 +300,7 @@ __device__ __forceinline__ void store_out8_f8(const GemmOut& o, int m, int n, fl
       for (int t = 0; t < 8; ++t) {
         const float x = sd[t];   // d/dx gelu(x) = Phi(x) + x phi(x), x = the saved pre-activation (load_side4)
         v[t] *= 0.5f * (1.0f + erf_fast(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+        v[t] = __builtin_amdgcn_fmed3f(v[t], -kF16Max, kF16Max);   // a gradient plane: saturate rather than overflow fp16 (common.h f16f8x4 SAT)
       }
     } else {
 #pragma unroll
@@ -1361,6 +1362,11 @@ int launch_epi(GemmArgs a, int prec, hipStream_t s) {
   int tile = g_force_tile;
   if (!tile) tile = (a.N % 256 == 0 && t256 >= kSlots) ? 256 : (t128 >= kSlots ? 128 : 64);
   if (tile == 256 && a.N % 256 != 0) tile = 128;
+  if (prec == PREC_F16) {        // one fp16 product (measurement mode): the single-product kernels on fp16 planes
+    if (tile == 256) return launch_one<1, 64, EPI, CfgW4, true>(a, s);
+    if (tile == 128) return launch_one<1, 64, EPI, Cfg128, true>(a, s);
+    return launch_one<1, 64, EPI, Cfg64, true>(a, s);
+  }
   if (tile == 256) return terms == 3 ? launch_one<3, 32, EPI, CfgW4>(a, s) : launch_one<1, 64, EPI, CfgW4>(a, s);
   if (tile == 128) return terms == 3 ? launch_one<3, 32, EPI, Cfg128>(a, s) : launch_one<1, 64, EPI, Cfg128>(a, s);
   // few tiles per CU: the K loop is latency-bound (one barrier + one global round trip per K-tile), so the deeper 64-wide
@@ -1446,7 +1452,7 @@ int launch_gemm(awt_ctx* c, int M, int N, const GemmSeg* segs, int nseg, int pre
                 hipStream_t s) {
   AWT_REQUIRE(M > 0 && N > 0 && N % 128 == 0, AWT_ERR_INVALID, "gemm: N must be a positive multiple of 128");
   AWT_REQUIRE(nseg >= 1 && nseg <= kMaxSeg, AWT_ERR_INVALID, "gemm: 1..3 K-segments");
-  AWT_REQUIRE(prec == PREC_BF16 || prec == PREC_BF16X3 || prec == PREC_F16X3 || prec == PREC_F16F8 || prec == PREC_F16F6, AWT_ERR_INVALID, "gemm: unknown operand precision");
+  AWT_REQUIRE(prec == PREC_BF16 || prec == PREC_F16 || prec == PREC_BF16X3 || prec == PREC_F16X3 || prec == PREC_F16F8 || prec == PREC_F16F6, AWT_ERR_INVALID, "gemm: unknown operand precision");
   const int terms = prec_products(prec);
   AWT_REQUIRE(c && c->zeros, AWT_ERR_INVALID, "gemm: context without a zero page");
   static const bool env_read = [] { if (const char* e = getenv("AWT_GEMM_GROUP_N")) g_group_n = std::max(0, atoi(e)); return true; }();   // tile-order experiments (tools/)

@@ -84,6 +84,14 @@ class AwtComm:
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().awt_allreduce_sum_f32(self.handle, _lib.ptr(flat), flat.numel(), _lib.stream_handle()))
 
+    def bucket_stats(self, enable: bool = True):
+        """[(milliseconds on the side stream, bytes)] of the bucket reductions the native backward issued since the last call (include/awt.h
+        awt_comm_bucket_stats); `enable` keeps / stops the recording."""
+        from . import _lib
+        ms = (C.c_double * 8)(); nb = (C.c_int64 * 8)(); n = C.c_int(0)
+        _lib.check(_lib.lib().awt_comm_bucket_stats(self.handle, 1 if enable else 0, ms, nb, 8, C.byref(n)))
+        return [(float(ms[i]), int(nb[i])) for i in range(n.value)]
+
     def close(self) -> None:
         if self.handle is not None:
             from . import _lib

@@ -32,7 +32,7 @@ from .weights import EncoderConfig, LoraSpec, encoder_param_shapes, init_encoder
 #   bf16x3  split-bf16, three bf16 MFMAs (2^-17 per operand; the training path's format)
 #   fp16x3  split-fp16, three fp16 MFMAs (2^-23 per operand: within fp32's own noise of the reference, also under 30x outlier gains)
 #   f16f8   fp16 main product + the two cross terms on the block-scaled e4m3 MFMA: two MFMA-equivalents (2^-16 per operand)
-PRECISIONS = {"bf16": 1, "bf16x3": 3, "fp16x3": 4, "f16f8": 5}
+PRECISIONS = {"bf16": 1, "fp16": 2, "bf16x3": 3, "fp16x3": 4, "f16f8": 5}   # "bf16" / "fp16": one product per fragment pair, measurement modes that miss the 1e-3 bound
 DEFAULT_PRECISION = "f16f8"
 
 
@@ -140,8 +140,11 @@ def _attach(root: nn.Module, dotted: str, p: nn.Parameter, epoch=None) -> None:
 class NativeWhisperEncoder(nn.Module):
     def __init__(self, cfg: EncoderConfig, precision: Optional[str] = None, lora: Optional[LoraSpec] = None,
                  device: str = "cuda", chunk_clips: int = 0, seed: Optional[int] = 0, init_profile: str = "hf",
-                 trainable: bool = False, backward_precision: Optional[str] = None):
+                 trainable: bool = False, backward_precision: Optional[str] = None, probe_clips=None):
         super().__init__()
+        # probe_clips (precision=None only): the caller's own audio -- 1-D float arrays / tensors at 16 kHz, e.g. a few clips of the data to be encoded --
+        # joins the two synthetic clips of the load-time precision probe, so that the measured decision sees what the checkpoint does on real input
+        self.probe_clips = [np.asarray(c.detach().cpu() if isinstance(c, torch.Tensor) else c, dtype=np.float32).reshape(-1) for c in (probe_clips or [])]
         # precision=None: training keeps bf16 planes; inference takes the fastest mode that meets the 1e-3 bound for the weights at hand --
         # f16f8, unless the checkpoint has outlier channels (choose_precision), where the 15-bit scheme's relative error turns into
         # absolute errors above the bound and the split-fp16 mode is used instead.  Re-decided when base weights change.
@@ -236,11 +239,16 @@ class NativeWhisperEncoder(nn.Module):
         from .feature_extraction import logmel_whisper_device
         from .weights import unit_variates
         n = self.cfg.n_frames * 160
-        pcm = np.zeros((2, n), dtype=np.float32)
+        extra = self.probe_clips[:6]                                  # the probe stays a handful of clips
+        pcm = np.zeros((2 + len(extra), n), dtype=np.float32)
         clip = synth.pcm_i16_to_f32(synth.synth_clips_i16(1, seed=1234, first=0)[0])
         m = min(n, clip.size)
         pcm[0, :m] = clip[:m]
         pcm[1, :m] = (0.1 * unit_variates("precision_probe", m, 0)).astype(np.float32)
+        for i, c in enumerate(extra):                                 # the caller's audio, zero-padded / truncated like any clip
+            k = min(n, c.size)
+            pcm[2 + i, :k] = c[:k]
+            m = max(m, k)
         return logmel_whisper_device(torch.from_numpy(pcm).to(self.device), max_valid=m, n_frames=self.cfg.n_frames, n_mels=self.cfg.n_mels)
 
     def _decide_precision(self) -> str:
@@ -269,7 +277,9 @@ class NativeWhisperEncoder(nn.Module):
         dist = float((outs[DEFAULT_PRECISION] - outs["fp16x3"]).abs().max())
         finite = bool(torch.isfinite(outs[DEFAULT_PRECISION]).all())
         choice = DEFAULT_PRECISION if (finite and dist < self.PROBE_TOL) else "fp16x3"
-        self.precision_report.update({"probe_max_abs_f16f8_vs_fp16x3": dist, "probe_tolerance": self.PROBE_TOL, "precision": choice, "decided_by": "probe"})
+        per_clip = (outs[DEFAULT_PRECISION] - outs["fp16x3"]).abs().flatten(1).amax(dim=1).tolist()
+        self.precision_report.update({"probe_max_abs_f16f8_vs_fp16x3": dist, "probe_tolerance": self.PROBE_TOL, "precision": choice, "decided_by": "probe",
+                                      "probe_clips": {"synthetic": 2, "caller": int(feats.shape[0]) - 2}, "probe_max_abs_per_clip": [float(x) for x in per_clip]})
         for prec, (h, synced) in handles.items():
             if prec == choice:
                 self._handle, self._synced = h, synced

@@ -412,6 +412,31 @@ class Seq2SeqTrainer:
         elif world > 1:
             self.exchange = "torch.distributed all_reduce (%s) on the flat buffer" % backend
 
+    def exchange_report(self):
+        """What the last steps' gradient exchange did, for bench.py's multi-GPU lines: the transport, the ranks RCCL saw, and -- under libawt's
+        communicator -- the side-stream time and size of every bucket reduction since the previous call (recording starts with the first call)."""
+        rep = {"transport": self.exchange, "world": world_size(), "rccl_ranks": self.comm.world if self.comm is not None else 0,
+               "flat_grad_elems": int(self.bucket.numel)}
+        if self.comm is not None:
+            spans = self.comm.bucket_stats(True)
+            rep["buckets"] = [{"ms": round(ms, 4), "bytes": nb} for ms, nb in spans]
+            rep["note"] = ("HIP events on the communicator's side stream around each ncclAllReduce(ncclAvg) of a finished layer group's adapter gradients, "
+                           "issued inside the native backward; empty on the first call (recording starts with it)")
+        return rep
+
+    def exchange_checksums(self, R=None):
+        """fp64 sum and sum of squares of this rank's flat gradient buffer AFTER the exchange (equal on every rank iff the all-reduce ran), gathered over
+        the ranks when a process group exists: [[sum, sumsq], ...] by rank."""
+        import torch.distributed as dist
+        flat = self.bucket.flat.detach().double()
+        mine = torch.stack([flat.sum(), (flat * flat).sum()])
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            t = mine if dist.get_backend() == "nccl" else mine.cpu()
+            out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+            dist.all_gather(out, t)
+            return [[float(x[0]), float(x[1])] for x in out]
+        return [[float(mine[0]), float(mine[1])]]
+
     def training_step(self, batch) -> float:
         """One optimizer step: forward + backward over `gradient_accumulation_steps` micro-batches (a single dict, or a list
         of that many dicts), ONE in-place mean all-reduce of the flat adapter-gradient buffer (inside the last native

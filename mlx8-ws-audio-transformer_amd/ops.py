@@ -8,7 +8,7 @@ import torch
 
 from . import _lib
 
-_TERMS = {"bf16": 1, "bf16x3": 3, "fp16x3": 4, "f16f8": 5, "f16f6": 6}   # common.h PREC_* (f16f6: experimental, `linear` only)
+_TERMS = {"bf16": 1, "fp16": 2, "bf16x3": 3, "fp16x3": 4, "f16f8": 5, "f16f6": 6}   # common.h PREC_* (f16f6: experimental, `linear` only)
 
 
 def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, precision: str = "bf16x3") -> torch.Tensor:

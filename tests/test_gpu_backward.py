@@ -197,3 +197,34 @@ def test_f16f8_mlp_backward_rejects_unsupported_configurations():
         NativeWhisperEncoder(cfg, precision="bf16x3", lora=wts.LoraSpec(r=8, alpha=16.0, targets=("q_proj", "fc1")), trainable=True, backward_precision="f16f8")
     with pytest.raises(ValueError):                          # inference encoders have no backward
         NativeWhisperEncoder(cfg, precision="bf16x3", lora=wts.LoraSpec(r=8, alpha=16.0, targets=("q_proj",)), backward_precision="f16f8")
+
+
+def test_f16f8_mlp_backward_saturates_instead_of_overflowing_on_an_outlier_gain():
+    """the gradient scale 2^k of the f16f8 backward is chosen from max |d loss / d hidden| alone; an intermediate gradient far above it (LayerNorm
+    backward through an outlier gain of a lower layer) used to overflow the fp16 gradient plane -> inf, -inf residual, NaN adapter gradients that AdamW
+    would bake in.  The gradient planes now saturate at fp16's largest finite value: every adapter gradient stays finite, and the layers ABOVE the outlier
+    (whose gradients never pass through it) still match the split-bf16 backward."""
+    from mlx8_ws_audio_transformer_amd.encoder import NativeWhisperEncoder
+    cfg = wts.config("tiny", True)
+    spec = wts.LoraSpec(r=8, alpha=16.0, targets=("q_proj", "v_proj"))
+    W = {k: v.copy() for k, v in wts.init_encoder_weights(cfg, 0, "test").items()}
+    W["layers.1.final_layer_norm.weight"][7] = 3.0e4                    # an extreme gain on one channel of layer 1's MLP LayerNorm
+    LW = wts.init_lora_weights(cfg, spec, 0, zero_b=False)
+    B = 2
+    mel = oracle_mel.whisper_logmel(piano_clips_f32(B), n_samples=cfg.n_frames * 160)
+    dout = (wts.unit_variates("dout", B * cfg.max_source_positions * cfg.d_model, 3).reshape(B, cfg.max_source_positions, cfg.d_model)
+            / np.sqrt(cfg.max_source_positions)).astype(np.float32)
+    got = {}
+    for bp in (None, "f16f8"):
+        enc = NativeWhisperEncoder(cfg, precision="bf16x3", lora=spec, trainable=True, seed=0, init_profile="test", backward_precision=bp)
+        enc.load_state_dict({k: torch.from_numpy(v) for k, v in {**W, **LW}.items()})
+        out = enc(torch.from_numpy(mel).cuda()).last_hidden_state
+        (out * torch.from_numpy(dout).cuda()).sum().backward()
+        got[bp] = {n: p.grad.cpu().numpy() for n, p in enc.named_parameters() if "lora_" in n}
+    for n, g in got["f16f8"].items():
+        assert np.isfinite(g).all(), n
+    upper = [n for n in got[None] if any(n.startswith("layers.%d." % li) for li in (2, 3))]
+    assert upper
+    for n in upper:
+        scale = max(np.abs(got[None][n]).max(), 1e-30)
+        assert np.abs(got["f16f8"][n] - got[None][n]).max() / scale < 5e-3, n

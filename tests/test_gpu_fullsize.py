@@ -124,3 +124,53 @@ def test_b64_training_steps_reduce_the_loss(step64):
     # the gradients never left the flat buffer: every adapter .grad is still a view of it
     assert tr.bucket.flat.data_ptr() == flat_ptr and tr.bucket.bind(keep=True) == 0
     assert model.encoder.lora_parameters_library_order()[0].grad.data_ptr() == flat_ptr
+
+
+# ---------------------------------------------------------------- BASELINE.json configs[3], one rank's share: LoRA r = 16, 64 clips per GPU (global batch 512 over 8 GPUs)
+def test_r16_b64_per_rank_step_of_the_dp8_configuration():
+    """What ONE rank of configs[3] runs: r = 16 adapters on q_proj / v_proj (589 824 gradient elements = 2.36 MB, the buffer the 8-GPU run all-reduces),
+    64 clips.  On this one GPU the exchange goes through libawt's RCCL communicator with a single rank (ncclAvg over one rank = identity), issued
+    inside the backward on the side stream: the step must fit in memory, time its two bucket reductions, leave the flat buffer bit-identical to a
+    run without the communicator, and be bit-reproducible."""
+    from mlx8_ws_audio_transformer_amd.feature_extraction import logmel_whisper_device
+    from mlx8_ws_audio_transformer_amd.finetune import Seq2SeqTrainer, Seq2SeqTrainingArguments, WhisperLoRAModel
+    cfg = wts.config("small")
+    pcm = torch.from_numpy(synth.synth_clips_i16(64, seed=1234, first=300)).cuda()
+    feats = logmel_whisper_device(pcm, n_frames=cfg.n_frames)
+    g = torch.Generator().manual_seed(1)
+    labels = torch.randint(0, 51864, (64, 12), generator=g); labels[:, 0] = 50258
+    labels = labels.cuda()
+
+    def run(native_comm):
+        torch.manual_seed(0)
+        model = WhisperLoRAModel(cfg, wts.LoraSpec(r=16, alpha=16.0), seed=0)
+        with torch.no_grad():
+            for p in model.lora_parameters():      # non-zero B so that both adapter matrices receive gradient
+                if p.shape[1] == 16:
+                    p.copy_(torch.from_numpy((0.02 * wts.unit_variates("r16", p.numel(), 1)).reshape(p.shape).astype(np.float32)))
+        args = Seq2SeqTrainingArguments(per_device_train_batch_size=64, learning_rate=1e-4, warmup_steps=0, max_steps=10, predict_with_generate=False)
+        tr = Seq2SeqTrainer(args=args, model=model)
+        if native_comm:
+            tr._setup_exchange(force_native=True)
+        assert tr.bucket.numel == 12 * 2 * 2 * 16 * 768 == 589824
+        rep0 = tr.exchange_report()
+        loss = tr.training_step({"input_features": feats, "labels": labels})
+        rep = tr.exchange_report()
+        flat = tr.bucket.flat.detach().clone()
+        sums = tr.exchange_checksums()
+        peak = torch.cuda.max_memory_allocated() / 2 ** 30
+        del tr, model
+        torch.cuda.empty_cache()
+        return loss, flat, rep0, rep, sums, peak
+
+    loss_a, flat_a, _, rep_plain, _, _ = run(False)
+    loss_b, flat_b, rep0, rep, sums, peak = run(True)
+    loss_c, flat_c, _, _, sums_c, _ = run(True)
+    print("r16 B64 step: loss %.5f, peak device memory %.1f GiB, exchange %s" % (loss_b, peak, rep))
+    assert np.isfinite(loss_b) and torch.isfinite(flat_b).all() and float(flat_b.abs().max()) > 0
+    assert rep_plain["rccl_ranks"] == 0 and rep["rccl_ranks"] == 1 and rep["flat_grad_elems"] == 589824
+    assert rep0.get("buckets") == [] and len(rep["buckets"]) == 2                      # two layer groups, each timed on the side stream
+    assert sum(b["bytes"] for b in rep["buckets"]) == 589824 * 4 and all(b["ms"] >= 0 for b in rep["buckets"])
+    assert torch.equal(flat_a, flat_b) and loss_a == loss_b                            # a one-rank ncclAvg is the identity
+    assert torch.equal(flat_b, flat_c) and sums == sums_c                              # bit-reproducible, checksum included
+    assert peak < 200.0
