@@ -315,6 +315,16 @@ int awt_op_attention_small(awt_ctx* c, const float* q, int ldq, const float* k, 
 int awt_op_attention_small_backward(awt_ctx* c, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o,
                                     const float* dout, int ldo, const float* lse, float* delta, float* dq, float* dk, float* dv, int B,
                                     int H, int Lq, int Sk, int causal, int causal_off, void* stream);
+/* The same pair with attention-probability dropout, what torch.nn.MultiheadAttention(dropout = p) applies in train()
+ * (/root/reference/.charles/spectrogram.py:977-985): P <- P * keep / (1 - p) after the softmax, before P V.  keep is a pure function of
+ * (seed, batch * H + head, query, key) -- splitmix64 of ((bh * Lq + i) * Sk + j) + seed * 0x9E3779B97F4A7C15 + 0x632BE59BD9B4E019, top 24 bits
+ * as a uniform in [0, 1), kept when >= p -- regenerated by the forward and both backward kernels from the same (drop_p, seed), never stored;
+ * urbansound_classifier.attention_keep_mask restates it on the host for tests.  drop_p = 0 is the plain pair. */
+int awt_op_attention_small_dropout(awt_ctx* c, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo,
+                                   float* lse, int B, int H, int Lq, int Sk, int causal, int causal_off, float drop_p, uint64_t seed, void* stream);
+int awt_op_attention_small_backward_dropout(awt_ctx* c, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o,
+                                            const float* dout, int ldo, const float* lse, float* delta, float* dq, float* dk, float* dv, int B,
+                                            int H, int Lq, int Sk, int causal, int causal_off, float drop_p, uint64_t seed, void* stream);
 
 /* Process-wide tuning / test hooks.  key "gemm_tile": 0 = choose the GEMM block tile from the shape (default), 64 / 128 / 256 =
  * force the 64 x 128, 128 x 128 or 128 x 256 tile (256 falls back to 128 when N is not a multiple of 256) so that tests can

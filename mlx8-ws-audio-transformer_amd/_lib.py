@@ -102,6 +102,8 @@ _SIGNATURES = {
     "awt_op_cross_entropy": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "awt_op_attention_small": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "awt_op_attention_small_backward": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "awt_op_attention_small_dropout": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, C.c_float, C.c_uint64, _vp]),
+    "awt_op_attention_small_backward_dropout": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, C.c_float, C.c_uint64, _vp]),
     "awt_tuning_set": (_i, [C.c_char_p, _i]),
     "awt_prof_enable": (_i, [_vp, _i]),
     "awt_prof_collect": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(C.c_double)]),

@@ -204,7 +204,20 @@ struct SmallAttn {
   const float *q, *k, *v; float* o; float* lse;
   const float *dout; float *dq, *dk, *dv; float* delta;
   int B, H, Lq, Sk, ldq, ldk, ldv, ldo, causal, causal_off;
+  // attention-probability dropout (torch.nn.MultiheadAttention(dropout=p) in train(): /root/reference/.charles/spectrogram.py:977-985): the softmax
+  // output P is multiplied by a keep mask / (1 - p) before P V.  The mask is a pure function of (seed, batch-head, query, key) -- splitmix64 of the flat
+  // index, top 24 bits against p -- so the forward and both backward kernels regenerate it instead of storing B H Lq Sk bytes, and a host-side
+  // restatement of the same function gives tests the identical mask.  drop_p = 0: no dropout (inv_keep = 1).
+  float drop_p, inv_keep; unsigned long long seed;
 };
+__device__ __forceinline__ float drop_keep(const SmallAttn& a, int bh, int i, int j) {
+  if (a.drop_p <= 0.f) return 1.0f;
+  unsigned long long z = ((unsigned long long)((long long)bh * a.Lq + i) * (unsigned long long)a.Sk + (unsigned long long)j) + a.seed * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return ((float)(unsigned)(z >> 40) * (1.0f / 16777216.0f) >= a.drop_p) ? a.inv_keep : 0.0f;
+}
 
 __device__ __forceinline__ float wave_max(float x) {
 #pragma unroll
@@ -326,7 +339,7 @@ __global__ __launch_bounds__(256) void small_attn_fwd_kernel(SmallAttn a) {
       l[i] = l[i] * alpha + wave_sum(p);
       m[i] = m_new;
       o[i] *= alpha;
-      ps[wave][i][lane] = p;
+      ps[wave][i][lane] = p * drop_keep(a, bh, i0 + i, j);          // the row sum l keeps the undropped p: dropout acts on the normalised probabilities
     }
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -409,7 +422,7 @@ __global__ __launch_bounds__(256) void small_attn_dq_kernel(SmallAttn a) {
         dp += u.x * v[e] + u.y * v[e + 1] + u.z * v[e + 2] + u.w * v[e + 3];
       }
       const bool ok = j <= kmax && i < nq && (!a.causal || j <= i0 + i + a.causal_off);
-      dss[wave][i][lane] = ok ? __expf(s - lses[i]) * (dp - deltas[i]) : 0.f;
+      dss[wave][i][lane] = ok ? __expf(s - lses[i]) * (dp * drop_keep(a, bh, i0 + i, j) - deltas[i]) : 0.f;   // dP = keep dP'; delta = dO . O = sum_j P_j dP_j either way
     }
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -492,12 +505,13 @@ __global__ __launch_bounds__(64) void small_attn_dkv_kernel(SmallAttn a) {
     }
     const bool on = live && i >= i0;
     const float p = on ? __expf(s * 0.125f - a.lse[row]) : 0.f;
-    const float ds = p * (dp - a.delta[row]) * 0.125f;
+    const float keep = drop_keep(a, bh, i, j);
+    const float ds = p * (dp * keep - a.delta[row]) * 0.125f;
 #pragma unroll
     for (int e = 0; e < 64; e += 4) {
       const float4 t = *reinterpret_cast<const float4*>(qr + e), u = *reinterpret_cast<const float4*>(gr + e);
       dk[e] += ds * t.x; dk[e + 1] += ds * t.y; dk[e + 2] += ds * t.z; dk[e + 3] += ds * t.w;
-      dv[e] += p * u.x; dv[e + 1] += p * u.y; dv[e + 2] += p * u.z; dv[e + 3] += p * u.w;
+      dv[e] += p * keep * u.x; dv[e + 1] += p * keep * u.y; dv[e + 2] += p * keep * u.z; dv[e + 3] += p * keep * u.w;
     }
   }
   store_tile(a.dk, a.ldk, dk);
@@ -509,6 +523,7 @@ int check_small(const SmallAttn& a, const char* who) {
   AWT_REQUIRE(a.ldq % 4 == 0 && a.ldk % 4 == 0 && a.ldv % 4 == 0 && a.ldo % 4 == 0 && a.ldq >= 64 * a.H && a.ldk >= 64 * a.H && a.ldv >= 64 * a.H && a.ldo >= 64 * a.H,
               AWT_ERR_INVALID, std::string(who) + ": row strides must be multiples of 4 and cover H * 64 columns");
   AWT_REQUIRE((int64_t)a.B * a.H * a.Lq < (1ll << 31), AWT_ERR_INVALID, std::string(who) + ": too many query rows");
+  AWT_REQUIRE(a.drop_p >= 0.f && a.drop_p < 1.f, AWT_ERR_INVALID, std::string(who) + ": dropout probability must be in [0, 1)");
   return AWT_OK;
 }
 
@@ -572,24 +587,34 @@ extern "C" int awt_op_cross_entropy(awt_ctx* c, const float* logits, const int64
   return AWT_OK;
 }
 
-extern "C" int awt_op_attention_small(awt_ctx* c, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo,
-                                      float* lse, int B, int H, int Lq, int Sk, int causal, int causal_off, void* stream) {
+extern "C" int awt_op_attention_small_dropout(awt_ctx* c, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo,
+                                              float* lse, int B, int H, int Lq, int Sk, int causal, int causal_off, float drop_p, uint64_t seed, void* stream) {
   AWT_REQUIRE(c && q && k && v && o, AWT_ERR_INVALID, "op_attention_small: null argument");
-  SmallAttn a{q, k, v, o, lse, nullptr, nullptr, nullptr, nullptr, nullptr, B, H, Lq, Sk, ldq, ldk, ldv, ldo, causal, causal_off};
+  SmallAttn a{q, k, v, o, lse, nullptr, nullptr, nullptr, nullptr, nullptr, B, H, Lq, Sk, ldq, ldk, ldv, ldo, causal, causal_off, drop_p, drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f, seed};
   int rc = check_small(a, "op_attention_small"); if (rc) return rc;
   hipLaunchKernelGGL(small_attn_fwd_kernel, dim3(B * H, (Lq + QB - 1) / QB), dim3(256), 0, (hipStream_t)stream, a);
   AWT_HIP_CHECK(hipGetLastError());
   return AWT_OK;
 }
-extern "C" int awt_op_attention_small_backward(awt_ctx* c, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o,
-                                               const float* dout, int ldo, const float* lse, float* delta, float* dq, float* dk, float* dv, int B,
-                                               int H, int Lq, int Sk, int causal, int causal_off, void* stream) {
+extern "C" int awt_op_attention_small(awt_ctx* c, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo,
+                                      float* lse, int B, int H, int Lq, int Sk, int causal, int causal_off, void* stream) {
+  return awt_op_attention_small_dropout(c, q, ldq, k, ldk, v, ldv, o, ldo, lse, B, H, Lq, Sk, causal, causal_off, 0.0f, 0, stream);
+}
+extern "C" int awt_op_attention_small_backward_dropout(awt_ctx* c, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o,
+                                                       const float* dout, int ldo, const float* lse, float* delta, float* dq, float* dk, float* dv, int B,
+                                                       int H, int Lq, int Sk, int causal, int causal_off, float drop_p, uint64_t seed, void* stream) {
   AWT_REQUIRE(c && q && k && v && o && dout && lse && delta && dq && dk && dv, AWT_ERR_INVALID, "op_attention_small_backward: null argument");
-  SmallAttn a{q, k, v, const_cast<float*>(o), const_cast<float*>(lse), dout, dq, dk, dv, delta, B, H, Lq, Sk, ldq, ldk, ldv, ldo, causal, causal_off};
+  SmallAttn a{q, k, v, const_cast<float*>(o), const_cast<float*>(lse), dout, dq, dk, dv, delta, B, H, Lq, Sk, ldq, ldk, ldv, ldo, causal, causal_off, drop_p,
+              drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f, seed};
   int rc = check_small(a, "op_attention_small_backward"); if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(small_attn_dq_kernel, dim3(B * H, (Lq + QB - 1) / QB), dim3(256), 0, s, a);
   hipLaunchKernelGGL(small_attn_dkv_kernel, dim3(B * H * ((Sk + 63) / 64)), dim3(64), 0, s, a);
   AWT_HIP_CHECK(hipGetLastError());
   return AWT_OK;
+}
+extern "C" int awt_op_attention_small_backward(awt_ctx* c, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o,
+                                               const float* dout, int ldo, const float* lse, float* delta, float* dq, float* dk, float* dv, int B,
+                                               int H, int Lq, int Sk, int causal, int causal_off, void* stream) {
+  return awt_op_attention_small_backward_dropout(c, q, ldq, k, ldk, v, ldv, o, dout, ldo, lse, delta, dq, dk, dv, B, H, Lq, Sk, causal, causal_off, 0.0f, 0, stream);
 }

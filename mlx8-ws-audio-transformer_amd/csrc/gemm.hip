@@ -102,9 +102,6 @@ struct Stager {
   int si, kk, nk;
 
   __device__ __forceinline__ void open_segment(const GemmArgs& g, int seg, int m0, int n0, int wc, int wave, int lane) {
-#ifdef AWT_DIAG_SAME_TILE   // every workgroup streams the same operand tiles: 100 % L2 hits (timing-only)
-    m0 = 0; n0 = 0;
-#endif
     si = seg; kk = 0;
     const GemmSeg& sg = g.seg[seg];
     nk = sg.K / BK;
@@ -132,20 +129,16 @@ struct Stager {
   __device__ __forceinline__ void issue(const GemmArgs& g, char* stage_base, int wave, bf16x8 (&nbh)[T::KS][CFG::TN], bf16x8 (&nbl)[T::KS][CFG::TN]) {
     static_assert(OP >= 0 && OP < T::NA + T::NB, "operation index");
     if constexpr (OP < T::NA) {
-#ifndef AWT_DIAG_NO_DMA   // AWT_DIAG_*: timing-only builds of tools/build_variants.sh (wrong results), never shipped
       constexpr int plane = OP % T::NP, it = OP / T::NP;
       char* dst = stage_base + (it * T::THREADS + wave * 64) * 16 + plane * T::PLANE_A;
       const bf16_t* src = plane == 0 ? a_hi[it] : a_lo[it];
       glds16(src ? (const void*)(src + kk * BK) : (const void*)g.zeros, dst);
-#endif
     } else {
-#ifndef AWT_DIAG_NO_WLOAD
       constexpr int q = OP - T::NA;
       constexpr int plane = q % T::NPW, r = q / T::NPW, j = r % CFG::TN, ks = r / CFG::TN;
       const int64_t off = (int64_t)j * w_tile_stride + (int64_t)(kk * T::KS + ks) * 512;
       if (plane == 0) nbh[ks][j] = *reinterpret_cast<const bf16x8*>(w_hi + off);
       else nbl[ks][j] = *reinterpret_cast<const bf16x8*>(w_lo + off);
-#endif
     }
   }
   __device__ __forceinline__ void advance(const GemmArgs& g, int m0, int n0, int wc, int wave, int lane) {
@@ -182,9 +175,6 @@ __device__ __forceinline__ float4 load_side4(const GemmOut& o, int m, int n, int
 // FULL / b: as store_out8_f8 below (no per-row predicate inside a full tile; the lane's bias values are loaded once per tile)
 template <int EPI, int OP, bool FULL>
 __device__ __forceinline__ void store_out4(const GemmOut& o, int m, int n, float4 acc, float4 side, float4 b, int M) {
-#ifdef AWT_DIAG_NO_STORE   // timing-only: epilogue arithmetic kept alive, nothing written
-  if (acc.x != 123.456f) { asm volatile("" ::"v"(acc.y), "v"(side.x)); return; }
-#endif
   if constexpr (!FULL) { if (m >= M || n >= o.n_valid) return; }
   float v[4] = {acc.x, acc.y, acc.z, acc.w};
   const float sd[4] = {side.x, side.y, side.z, side.w};
@@ -262,9 +252,6 @@ __device__ __forceinline__ void store_out8_f8(const GemmOut& o, int m, int n, fl
   v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
   if (EPI == EPI_F32 || EPI == EPI_F32_RESID || EPI == EPI_F32_GELU_POS) {
     float* dst = o.f32 + (int64_t)m * o.ldo + n;
-#ifdef AWT_DIAG_NO_STORE
-    dst = o.f32 + (threadIdx.x & 63) * 8;
-#endif
 #pragma unroll
     for (int t = 0; t < 8; ++t) v[t] = EPI == EPI_F32_RESID ? v[t] + sd[t] : (EPI == EPI_F32_GELU_POS ? gelu_erf(v[t]) + sd[t] : v[t]);
     *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
@@ -311,9 +298,6 @@ __device__ __forceinline__ void store_out8_f8(const GemmOut& o, int m, int n, fl
   bf16_t h[8]; float l[8];
 #pragma unroll
   for (int t = 0; t < 8; ++t) { h[t] = f32_to_f16(v[t]); l[t] = v[t] - f16_to_f32(h[t]); }
-#ifdef AWT_DIAG_NO_STORE   // timing-only: every store instruction stays, but all waves write the same 1 KB per plane (L2-resident: no HBM write traffic)
-  off = (threadIdx.x & 63) * 8;
-#endif
   if constexpr (ILV) {   // interleaved lines (Act::ilv): the eight columns are a quarter q of one 128-byte line: fp16 bytes 16 q, hi8 64 + 8 q, lo8 96 + 8 q
     char* line = o.ilv + (off >> 5) * 128;
     const int q = (int)(off & 31) >> 3;
@@ -411,9 +395,7 @@ __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, 2) void gemm_kernel(GemmArg
     // step to arrive, instead of behind the next step's reads
     if (TERMS == 3) asm volatile("" ::"v"(ah[s & 1]), "v"(al[s & 1]));
     else asm volatile("" ::"v"(ah[s & 1]));
-#ifndef AWT_DIAG_NO_LDSREAD
     if constexpr (s + 1 < STEPS) load_a(cur, (s + 1) / TM, (s + 1) % TM, ah[(s + 1) & 1], al[(s + 1) & 1]);
-#endif
     if (has_next) {   // this step's share of the next K-tile's memory operations (never a burst: see the header)
       [&]<int... O>(std::integer_sequence<int, O...>) {
         ([&] {
@@ -445,10 +427,8 @@ __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, 2) void gemm_kernel(GemmArg
     load_a(cur, 0, 0, ah[0], al[0]);
     [&]<int... S>(std::integer_sequence<int, S...>) { (step(std::integral_constant<int, S>{}, cur, nxt, has_next), ...); }(std::make_integer_sequence<int, STEPS>{});
     if (has_next) st.advance(g, m0, n0, wc, wave, lane);
-#ifndef AWT_DIAG_NO_BARRIER
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-#endif
   }
 
   // epilogue: the C/D layout of the 16x16 MFMA (col = lane & 15, row = (lane >> 4) * 4 + reg) would give 2-4 byte
@@ -537,33 +517,45 @@ template <int N> __device__ __forceinline__ void wait_vm(bf16x8& f0, bf16x8& f1)
 template <int OFF>
 __device__ __forceinline__ bf16x8 lds_read16(unsigned addr) {
   bf16x8 v;
-#ifdef AWT_DIAG_NO_LDSREAD   // timing-only (wrong results): no A fragment reads from LDS (the counted lgkmcnt waits then pass at once)
-  asm volatile("; no ds_read (diag) %0 %1" : "=v"(v) : "v"(addr));
-#else
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
-#endif
   return v;
 }
 template <int N> __device__ __forceinline__ void lgkm_wait(bf16x8& f) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(N)); }
 template <int N> __device__ __forceinline__ void lgkm_wait(bf16x8& f0, bf16x8& f1) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f0), "+v"(f1) : "n"(N)); }
-#ifdef AWT_DIAG_MFMA16   // timing-only (wrong results, finite): every 32x32 MFMA is issued as the two 16x16 MFMAs of the same matrix-pipe cycles and operand registers
-// (v_mfma_f32_16x16x32_f16 for 32x32x16_f16, v_mfma_scale_f32_16x16x128_f8f6f4 for 32x32x64), each 16x16 sub-accumulator of a 32x32 block getting
-// what the real variant would give it: what VERDICT r2 item 1(c)'s kernel would issue, without its fragment layouts (profiles/r03_gemm_experiments.txt)
-__device__ __forceinline__ void diag_mfma16_f16(f32x16& acc, bf16x8 a, bf16x8 b, int ks) {
-  f32x4* s = reinterpret_cast<f32x4*>(&acc);
-  s[(2 * ks) & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), s[(2 * ks) & 3], 0, 0, 0);
-  s[(2 * ks + 1) & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), s[(2 * ks + 1) & 3], 0, 0, 0);
-}
-template <int SA, int SB>
-__device__ __forceinline__ void diag_mfma16_f8(f32x16& acc, i32x8 a, i32x8 b, int which) {
-  f32x4* s = reinterpret_cast<f32x4*>(&acc);
-  s[2 * which] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, s[2 * which], 0, 0, 0, SA, 0, SB);
-  s[2 * which + 1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, s[2 * which + 1], 0, 0, 0, SA, 0, SB);
-}
-#endif
 __device__ __forceinline__ i32x8 cat8(bf16x8 lo, bf16x8 hi) {
   return __builtin_shufflevector(__builtin_bit_cast(i32x4_t, lo), __builtin_bit_cast(i32x4_t, hi), 0, 1, 2, 3, 4, 5, 6, 7);
 }
+
+// The vector-memory operations a prefetching K-tile issues (for K-tile kt + 1), in program order -- vmcnt retires in this order, so every counted wait of the
+// K loop is "the operations issued after the one waited for":
+//     position 0 .. NDMA - 1                    the LDS-DMA pieces, DMA_PER_STEP of them ahead of each row tile's MFMAs of k-step 0
+//     position NDMA + ks TN + j  (ks < 4)       fp16 W fragment j of k-step ks into the register ring, issued behind k-step ks's last MFMAs
+//     position NDMA + 4 TN .. N - 1             the e4m3 W planes, issued behind the e4m3 part
+// A hand-written count that disagrees with this order waits for the wrong operation (garbage fragments, or -- during bring-up -- a load landing in registers
+// the epilogue had reused: a memory fault), so the counts are computed here and nowhere else.
+template <int TM, int TN, int NDMA, int NW8>
+struct F8IssueOrder {
+  static constexpr int NW16 = 4 * TN, N = NDMA + NW16 + NW8;
+  static constexpr int DMA_PER_STEP = (NDMA + TM - 1) / TM;
+  static constexpr int last_dma = NDMA - 1;
+  static constexpr int last_w16(int ks) { return NDMA + ks * TN + TN - 1; }
+  static constexpr int last_w8 = N - 1;
+  // operations of THIS K-tile already issued when k-step ks's first MFMA group (row tile 0) waits: its own share of the DMA pieces in k-step 0, else every
+  // DMA piece plus the ring reloads of the k-steps before it
+  static constexpr int issued_at_step(int ks) { return ks == 0 ? DMA_PER_STEP : NDMA + ks * TN; }
+  static constexpr int issued_at_f8 = NDMA + NW16;                    // ... when the e4m3 part starts
+  static constexpr int younger(int pos_prev_tile, int issued_now) { return (N - 1 - pos_prev_tile) + issued_now; }
+  // fp16 W fragments of k-step ks, loaded one K-tile ago: the rest of that K-tile's operations plus what this one has issued (PF) or nothing (last K-tile)
+  template <bool PF> static constexpr int w16_wait(int ks) { return younger(last_w16(ks), PF ? issued_at_step(ks) : 0); }
+  // e4m3 W planes, the previous K-tile's last operations
+  template <bool PF> static constexpr int w8_wait() { return younger(last_w8, PF ? issued_at_f8 : 0); }
+  // at the K-tile barrier, after this K-tile's last operation was issued: only its DMA pieces must have landed (AWT_GEMM_WDEC) / also its fp16 fragments
+  static constexpr int dma_wait_at_barrier() { return N - 1 - last_dma; }
+  static constexpr int w16_wait_at_barrier() { return N - 1 - last_w16(3); }
+  static_assert(w16_wait<true>(0) == 3 * TN + NW8 + DMA_PER_STEP && w16_wait<true>(3) == 3 * TN + NW8 + NDMA && w16_wait<false>(1) == 2 * TN + NW8, "w16 waits");
+  static_assert(w8_wait<true>() == NDMA + NW16 && w8_wait<false>() == 0 && dma_wait_at_barrier() == NW16 + NW8 && w16_wait_at_barrier() == NW8, "w8 / barrier waits");
+  static_assert(w16_wait<true>(3) <= 63, "vmcnt is a 6-bit count");
+};
 
 // WX: every weight of the (single) K segment is exactly representable in fp16 (true of checkpoints stored in half precision), so its lo plane is
 // zero and the x_hi w_lo cross term vanishes: one e4m3 MFMA per fragment pair (x_lo8 w_hi8) instead of two, and neither the A hi8 image nor the W lo8
@@ -616,11 +608,7 @@ __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, CFG::WM * CFG::WN == 4 ? 2 
   const char *w16b[TN], *w8b[TN], *wl8b[TN];       // block of n-tile j at the current K-tile
   const unsigned wl16 = lane * 16, wl32 = lane * 32;
   int si = 0, kk = 0, nk = 0;
-#ifdef AWT_DIAG_SAME_TILE   // every workgroup streams the operand tiles of tile (0, 0): 100 % L2 hits (timing-only, wrong results)
-  const int am0 = 0, an0 = 0;
-#else
   const int am0 = m0, an0 = n0;
-#endif
   auto open_segment = [&](int seg) {
     si = seg; kk = 0;
     const GemmSeg& sg = g.seg[seg];
@@ -673,9 +661,6 @@ __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, CFG::WM * CFG::WN == 4 ? 2 
   // DMA piece OP (0 .. NDMA - 1) of the K-tile the streams point at
   auto dma = [&](auto op_t, char* stage) {
     constexpr int OP = decltype(op_t)::value;
-#ifdef AWT_DIAG_NO_DMA      // timing-only (wrong results): no activation LDS-DMA after the prologue's
-    if (stage != smem) return;
-#endif
     if constexpr (OP < IT16) {
       const unsigned o = a16o[OP];
       glds16(o != kInvalid ? (const void*)(a16b + o) : (const void*)g.zeros, stage + (OP * NT + wave * 64) * 16);
@@ -691,21 +676,12 @@ __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, CFG::WM * CFG::WN == 4 ? 2 
 
   bf16x8 w16[4][TN];              // fp16 B fragments of the K-tile's four k-steps
   bf16x8 w8[TN][2], wl8[TN][2];   // e4m3 operands (32 bytes = two 16-byte halves)
-#ifdef AWT_DIAG_NO_WLOAD    // timing-only (wrong results): the weight fragments are loaded once, in the prologue
-  bool diag_w_loaded = false;
-#endif
   auto load_w16 = [&](auto ks_t) {
     constexpr int ks = decltype(ks_t)::value;
-#ifdef AWT_DIAG_NO_WLOAD
-    if (diag_w_loaded) return;
-#endif
 #pragma unroll
     for (int j = 0; j < TN; ++j) w16[ks][j] = gload16<ks * 1024>(wl16, w16b[j]);
   };
   auto load_w8 = [&]() {
-#ifdef AWT_DIAG_NO_WLOAD
-    if (diag_w_loaded) return;
-#endif
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       w8[j][0] = gload16<0>(wl32, w8b[j]); w8[j][1] = gload16<16>(wl32, w8b[j]);
@@ -715,26 +691,11 @@ __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, CFG::WM * CFG::WN == 4 ? 2 
 
   // ---- prologue: K-tile 0 into stage 0 and into the W registers
   open_segment(0);
-#ifdef AWT_DIAG_NO_PROLOGUE   // timing-only (wrong results): K-tile 0's operands are "already there" -- the upper bound of what a persistent workgroup
-  // that prefetches the next tile's first K-tile during its epilogue could hide (profiles/r03_gemm_experiments.txt)
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) w16[ks][j] = (bf16x8){};
-#pragma unroll
-  for (int j = 0; j < TN; ++j) { w8[j][0] = w8[j][1] = (bf16x8){}; if constexpr (!WX) { wl8[j][0] = wl8[j][1] = (bf16x8){}; } }
-  // stage 0 zeroed (uninitialised LDS would put NaNs into the outputs, and NaN data changes the power / clock of every later kernel)
-  for (int o = tid * 16; o < STAGE; o += NT * 16) *reinterpret_cast<uint4*>(smem + o) = make_uint4(0u, 0u, 0u, 0u);
-#else
   [&]<int... O>(std::integer_sequence<int, O...>) { (dma(std::integral_constant<int, O>{}, smem), ...); }(std::make_integer_sequence<int, NDMA>{});
   [&]<int... S>(std::integer_sequence<int, S...>) { (load_w16(std::integral_constant<int, S>{}), ...); }(std::make_integer_sequence<int, 4>{});
   load_w8();
   wait_vm<0>();
-#endif
   __builtin_amdgcn_s_barrier();
-#ifdef AWT_DIAG_NO_WLOAD
-  diag_w_loaded = true;
-#endif
 
   // A fragment offsets inside a stage: fp16 image row r, chunk (2 ks + half) ^ ((r >> 1) & 7); e4m3 images row r, chunks
   // (2 half + c) ^ ((r >> 2) & 3).  Row tile i adds a multiple of 32 rows, which leaves both swizzle terms unchanged.
@@ -748,6 +709,8 @@ __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, CFG::WM * CFG::WN == 4 ? 2 
   for (int c = 0; c < 2; ++c) a8a[c] = lds0 + PL16 + (wr * TM * 32 + r32) * 64 + (((2 * half + c) ^ ((r32 >> 2) & 3)) << 4);
 
   constexpr int DMA_PER_STEP = (NDMA + TM - 1) / TM;    // every DMA piece is issued during k-step 0, ahead of all W reloads
+  using ORD = F8IssueOrder<TM, TN, NDMA, NW8>;          // the issue order of the K-tile's memory operations and every counted wait derived from it
+  static_assert(ORD::DMA_PER_STEP == DMA_PER_STEP && ORD::NW16 == NW16, "issue-order table and kernel disagree");
   // One K-tile.  PF (compile time): prefetch K-tile kt + 1 (A by LDS-DMA into the other stage, W into the register ring).  The
   // last K-tile is instantiated without any load: a load still in flight when the loop ends would land in registers the
   // epilogue has already reused (the compiler cannot see that an inline-asm load completes later).
@@ -798,21 +761,17 @@ __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, CFG::WM * CFG::WN == 4 ? 2 
         // the fp16 W fragments of k-step ks were loaded a whole K-tile ago (ring); vmcnt retires in issue order, so the wait counts what was
         // issued since: the later k-steps' fragments of this K-tile (3 - ks) TN, its e4m3 planes NW8, and -- when prefetching -- the DMA
         // pieces (all of them from k-step 1 on, this step's share in k-step 0) and the ks TN fragments already reloaded for K-tile kt + 1
-        if constexpr (i == 0) wait_vm<(PF ? 3 * TN + NW8 + (ks == 0 ? DMA_PER_STEP : NDMA) : (3 - ks) * TN + NW8)>(w16[ks][0], w16[ks][1]);
+        if constexpr (i == 0) wait_vm<ORD::template w16_wait<PF>(ks)>(w16[ks][0], w16[ks][1]);
 #endif
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-#ifdef AWT_DIAG_MFMA16
-        for (int j = 0; j < TN; ++j) diag_mfma16_f16(acc[i][j], af[S % (AD + 1)], w16[ks][j], ks);
-#else
         for (int j = 0; j < TN; ++j) acc[i][j] = mfma32<true>(af[S % (AD + 1)], w16[ks][j], acc[i][j]);
-#endif
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (PF && i == TM - 1) load_w16(std::integral_constant<int, ks>{});     // ring: this k-step's registers, for K-tile kt + 1
       }(), ...);
     }(std::make_integer_sequence<int, 4 * TM>{});
     // ---- e4m3 part: its W registers were loaded a K-tile ago, behind this K-tile's NDMA + NW16 younger operations
-    if constexpr (PF) wait_vm<NDMA + NW16>(); else wait_vm<0>();
+    wait_vm<ORD::template w8_wait<PF>()>();
     if constexpr (!EARLY8) { if constexpr (!WX) read_x(std::integral_constant<int, 0>{}); read_y(std::integral_constant<int, 0>{}); }
     [&]<int... I>(std::integer_sequence<int, I...>) {
       ([&] {
@@ -821,11 +780,7 @@ __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, CFG::WM * CFG::WN == 4 ? 2 
           __builtin_amdgcn_sched_barrier(0);
           const i32x8 a8 = cat8(ax[0], ax[1]);
 #pragma unroll
-#ifdef AWT_DIAG_MFMA16
-          for (int j = 0; j < TN; ++j) diag_mfma16_f8<e8m0(-kF8Act), e8m0(-kF8Wgt - kF8Lo)>(acc[I][j], a8, cat8(wl8[j][0], wl8[j][1]), 0);
-#else
           for (int j = 0; j < TN; ++j) acc[I][j] = mfma32_f8<e8m0(-kF8Act), e8m0(-kF8Wgt - kF8Lo)>(a8, cat8(wl8[j][0], wl8[j][1]), acc[I][j]);
-#endif
           __builtin_amdgcn_sched_barrier(0);
           if constexpr (I + 1 < TM) read_x(std::integral_constant<int, I + 1>{});
         }
@@ -836,22 +791,14 @@ __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, CFG::WM * CFG::WN == 4 ? 2 
           __builtin_amdgcn_sched_barrier(0);
           const i32x8 al8 = cat8(yb[0], yb[1]);
 #pragma unroll
-#ifdef AWT_DIAG_MFMA16
-          for (int j = 0; j < TN; ++j) diag_mfma16_f8<e8m0(-kF8Act - kF8Lo), e8m0(-kF8Wgt)>(acc[I][j], al8, cat8(w8[j][0], w8[j][1]), 1);
-#else
           for (int j = 0; j < TN; ++j) acc[I][j] = mfma32_f8<e8m0(-kF8Act - kF8Lo), e8m0(-kF8Wgt)>(al8, cat8(w8[j][0], w8[j][1]), acc[I][j]);
-#endif
           __builtin_amdgcn_sched_barrier(0);
         } else {
           lgkm_wait<(I + 1 < TM ? 2 : 0)>(ay[0], ay[1]);    // younger: X(I + 1)
           __builtin_amdgcn_sched_barrier(0);
           const i32x8 al8 = cat8(ay[0], ay[1]);
 #pragma unroll
-#ifdef AWT_DIAG_MFMA16
-          for (int j = 0; j < TN; ++j) diag_mfma16_f8<e8m0(-kF8Act - kF8Lo), e8m0(-kF8Wgt)>(acc[I][j], al8, cat8(w8[j][0], w8[j][1]), 1);
-#else
           for (int j = 0; j < TN; ++j) acc[I][j] = mfma32_f8<e8m0(-kF8Act - kF8Lo), e8m0(-kF8Wgt)>(al8, cat8(w8[j][0], w8[j][1]), acc[I][j]);
-#endif
           __builtin_amdgcn_sched_barrier(0);
           if constexpr (I + 1 < TM) read_y(std::integral_constant<int, I + 1>{});
         }
@@ -862,10 +809,10 @@ __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, CFG::WM * CFG::WN == 4 ? 2 
 #if AWT_GEMM_WDEC
       // only the DMA pieces of K-tile kt + 1 must have landed before the barrier; its W fragments (NW16 + NW8 younger loads) stay in flight
       // across it and are waited for where they are consumed, a K-tile after their issue
-      wait_vm<NW16 + NW8>();
+      wait_vm<ORD::dma_wait_at_barrier()>();
 #else
       // the DMA pieces and the fp16 W fragments of K-tile kt + 1 are older than the NW8 e4m3 loads just issued
-      wait_vm<NW8>();
+      wait_vm<ORD::w16_wait_at_barrier()>();
 #endif
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -885,17 +832,6 @@ __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, CFG::WM * CFG::WN == 4 ? 2 
   // layout: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)); a lane then owns EIGHT consecutive columns of a row
   // (8 lanes per row, 8 rows per pass): 32-byte fp32 / 16-byte fp16 / 8-byte e4m3 stores, whole 256-byte row segments per plane.
   static_assert(TN == 2, "epilogue strips are 64 columns wide");
-#ifdef AWT_DIAG_NO_EPI      // timing-only build: the accumulators are consumed by one store per lane instead of the epilogue
-  { float sacc = 0.f;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int rr = 0; rr < 16; ++rr) sacc += acc[i][j][rr];
-    if (sacc == 123.456f) g.out.f32[0] = sacc;
-    return; }
-#endif
   constexpr int PITCH = 72;   // floats: 288-byte rows keep the two 16-byte reads of a lane 16-byte aligned
   float* patch = reinterpret_cast<float*>(smem) + wave * (32 * PITCH);      // 9216 B per wave
   const int c8 = (lane & 7) * 8, r8 = lane >> 3;

@@ -121,27 +121,29 @@ def gelu_backward(x, dy):
     return dx
 
 
-def attention_small(q, ldq, k, ldk, v, ldv, B, H, Lq, Sk, causal, causal_off, want_lse=True):
-    """q / k / v: (tensor, column offset in elements) pairs over row-major fp32 matrices; returns o [B * Lq, H * 64] and lse [B, H, Lq]."""
+def attention_small(q, ldq, k, ldk, v, ldv, B, H, Lq, Sk, causal, causal_off, want_lse=True, drop_p=0.0, seed=0):
+    """q / k / v: (tensor, column offset in elements) pairs over row-major fp32 matrices; returns o [B * Lq, H * 64] and lse [B, H, Lq].
+    drop_p > 0: attention-probability dropout with the seeded in-kernel mask (include/awt.h awt_op_attention_small_dropout)."""
     (qt, qo), (kt, ko), (vt, vo) = q, k, v
     o = torch.empty((B * Lq, H * 64), dtype=torch.float32, device=qt.device)
     lse = torch.empty((B, H, Lq), dtype=torch.float32, device=qt.device) if want_lse else None
     with torch.cuda.device(qt.device):
-        _lib.check(_lib.lib().awt_op_attention_small(_ctx(qt), qt.data_ptr() + 4 * qo, ldq, kt.data_ptr() + 4 * ko, ldk, vt.data_ptr() + 4 * vo, ldv,
-                                                     _lib.ptr(o), H * 64, _lib.ptr(lse), B, H, Lq, Sk, int(causal), int(causal_off), _lib.stream_handle()))
+        _lib.check(_lib.lib().awt_op_attention_small_dropout(_ctx(qt), qt.data_ptr() + 4 * qo, ldq, kt.data_ptr() + 4 * ko, ldk, vt.data_ptr() + 4 * vo, ldv,
+                                                             _lib.ptr(o), H * 64, _lib.ptr(lse), B, H, Lq, Sk, int(causal), int(causal_off), float(drop_p), int(seed),
+                                                             _lib.stream_handle()))
     return o, lse
 
 
-def attention_small_backward(q, ldq, k, ldk, v, ldv, o, dout, lse, dq, dk, dv, B, H, Lq, Sk, causal, causal_off):
+def attention_small_backward(q, ldq, k, ldk, v, ldv, o, dout, lse, dq, dk, dv, B, H, Lq, Sk, causal, causal_off, drop_p=0.0, seed=0):
     """Writes dq / dk / dv at (tensor, column offset) destinations laid out like q / k / v."""
     (qt, qo), (kt, ko), (vt, vo) = q, k, v
     (dqt, dqo), (dkt, dko), (dvt, dvo) = dq, dk, dv
     delta = torch.empty((B, H, Lq), dtype=torch.float32, device=qt.device)
     with torch.cuda.device(qt.device):
-        _lib.check(_lib.lib().awt_op_attention_small_backward(
+        _lib.check(_lib.lib().awt_op_attention_small_backward_dropout(
             _ctx(qt), qt.data_ptr() + 4 * qo, ldq, kt.data_ptr() + 4 * ko, ldk, vt.data_ptr() + 4 * vo, ldv, _lib.ptr(o), _lib.ptr(dout), H * 64, _lib.ptr(lse),
             _lib.ptr(delta), dqt.data_ptr() + 4 * dqo, dkt.data_ptr() + 4 * dko, dvt.data_ptr() + 4 * dvo, B, H, Lq, Sk, int(causal), int(causal_off),
-            _lib.stream_handle()))
+            float(drop_p), int(seed), _lib.stream_handle()))
 
 
 def gemm(x: torch.Tensor, w: torch.Tensor, precision: str = "bf16x3") -> torch.Tensor:

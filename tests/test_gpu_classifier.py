@@ -128,3 +128,49 @@ def test_train_transformer_learns_a_separable_toy_problem_and_matches_one_adam_s
     model.eval()
     xb, yb = batch()
     assert float((model(xb.cuda()).argmax(-1).cpu() == yb).float().mean()) >= 0.9
+
+
+@pytest.mark.parametrize("B,H,S,p", [(2, 3, 70, 0.25), (1, 4, 127, 0.1), (3, 2, 64, 0.5)])
+def test_attention_probability_dropout_matches_autograd_with_the_same_mask(B, H, S, p):
+    """`nn.TransformerEncoderLayer(dropout=p)` drops attention weights in train() (spectrogram.py:977-985).  The native attention pair
+    regenerates a seeded keep mask in its forward and both backward kernels; `attention_keep_mask` restates the mask on the host, and with that very
+    mask torch autograd must give the same output and the same dq / dk / dv."""
+    from mlx8_ws_audio_transformer_amd.urbansound_classifier import _Attention, attention_keep_mask
+    seed = 123456789 + S
+    qkv = torch.from_numpy(wts.unit_variates("drop.qkv", B * S * 3 * H * 64, 11).reshape(B * S, 3 * H * 64).astype(np.float32)).cuda().requires_grad_(True)
+    dout = torch.from_numpy(wts.unit_variates("drop.do", B * S * H * 64, 12).reshape(B * S, H * 64).astype(np.float32)).cuda()
+    o = _Attention.apply(qkv, B, H, S, p, seed)
+    o.backward(dout)
+    mask = attention_keep_mask(seed, B, H, S, S, p)
+    frac = float((mask > 0).float().mean())
+    assert abs(frac - (1 - p)) < 0.03, frac                                        # the mask really drops ~p of the weights
+    ref_in = qkv.detach().cpu().double().requires_grad_(True)
+    q, k, v = (ref_in.reshape(B, S, 3, H, 64)[:, :, i].permute(0, 2, 1, 3) for i in range(3))       # [B, H, S, 64]
+    P = torch.softmax(q @ k.transpose(2, 3) * 0.125, dim=-1) * mask.double()
+    want = (P @ v).permute(0, 2, 1, 3).reshape(B * S, H * 64)
+    want.backward(dout.cpu().double())
+    assert float((o.detach().cpu().double() - want.detach()).abs().max()) < 2e-5
+    g, w = qkv.grad.cpu().double(), ref_in.grad
+    assert float((g - w).abs().max()) < 2e-5 * max(1.0, float(w.abs().max()))
+    # p = 0 is the plain kernel pair, bit for bit
+    assert torch.equal(_Attention.apply(qkv.detach(), B, H, S, 0.0, seed), _Attention.apply(qkv.detach(), B, H, S))
+
+
+def test_train_mode_applies_attention_dropout_and_eval_caches_packed_weights():
+    """train(): with dropout > 0 two forwards differ (fresh seeds per layer and step, recorded in `last_attention_seeds`) and `torch.manual_seed` reproduces
+    a step; eval(): the weights are packed once per parameter version -- a second call reuses the handles, an in-place update re-packs."""
+    _, nat = _train_pair(64, 126, seed=3, dropout=0.3)
+    x = torch.from_numpy(wts.unit_variates("cls.xd", 2 * 64 * 126, 9).reshape(2, 64, 126).astype(np.float32)).cuda() * 2.0 - 4.0
+    torch.manual_seed(5); a = nat(x).detach().clone(); seeds_a = list(nat.last_attention_seeds)
+    b = nat(x).detach().clone()
+    torch.manual_seed(5); c = nat(x).detach().clone()
+    assert len(seeds_a) == 2 and all(s > 0 for s in seeds_a) and seeds_a[0] != seeds_a[1]
+    assert not torch.equal(a, b) and torch.equal(a, c)
+    nat.eval()
+    y0 = nat(x); handles = {k: id(v[1]) for k, v in nat._packed.items.items()}
+    y1 = nat(x)
+    assert torch.equal(y0, y1) and handles == {k: id(v[1]) for k, v in nat._packed.items.items()} and len(handles) >= 8
+    with torch.no_grad():
+        nat.head[3].weight.mul_(2.0)
+    y2 = nat(x)
+    assert not torch.equal(y0, y2) and id(nat._packed.items[id(nat.head[3].weight)][1]) != handles[id(nat.head[3].weight)]
