@@ -40,7 +40,13 @@ struct AttnArgs {
   int B, H, S;
 };
 
-__device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
+// Chunk swizzle of a [rows][64 x 16-bit] LDS image (128-byte rows, eight 16-byte chunks) that serves BOTH kinds of read: chunk ^ swz(row) with swz = the three
+// bits of row >> 1 with bits 0 and 2 exchanged.  ds_read_b128 of a 32x32x16 operand (16 distinct rows per 16-lane group, one chunk column) needs swz to be a
+// bijection of (row >> 1) & 7 over those rows -- any bit permutation is; ds_read_b64_tr_b16 (a 32-lane half takes four consecutive rows x four chunks) needs rows
+// r and r + 2 (256 bytes apart: the same banks) in different 64-byte halves of their rows, i.e. bit 2 of the swizzle must follow bit 0 of row >> 1.  With the
+// plain (row >> 1) & 7 used until round 3 every transposed read was a 2-way bank conflict (SQ_LDS_BANK_CONFLICT = 24 % of the f16f8 kernel's LDS-active cycles).
+// Consequences for the offsets below: rows + 8 flip bit 2 of row >> 1 = bit 0 of the swizzle (byte ^ 16), rows + 16 / + 32 change nothing.
+__device__ __forceinline__ int swz(int row) { const int x = (row >> 1) & 7; return (x & 2) | ((x & 1) << 2) | (x >> 2); }
 
 __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) { glds16_asm(gsrc, lds_wave_base); }   // common.h: invisible to hipcc's vmcnt bookkeeping
 
@@ -115,7 +121,7 @@ __global__ __launch_bounds__(kThreads, 2) void attention_kernel(AttnArgs a) {
   // change when a row moves by 16, so sub-tiles / k-steps / dim-tiles differ by constants or by one XOR bit.
   //   K fragment (row = 32 kt2 + ql, chunk 2 ks + half):  koff[ks] + 4096 kt2
   //   V^T blocks (key0 = 32 kt2 + 16 s + 4 (g >> 1) + qq, chunk 4 et + cc):  dim-tile et toggles chunk bit 2 (byte bit 6),
-  //   the +8-key block adds 1024 and toggles it back:  off0(et) = voff ^ (64 et),  off1(et) = (voff ^ 64 ^ (64 et)) + 1024
+  //   the +8-key block adds 1024 and flips the swizzle's bit 0:  off0(et) = voff ^ (64 et),  off1(et) = (off0(et) ^ 16) + 1024
   int koff[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) koff[ks] = ql * 128 + (((2 * ks + half) ^ swz(ql)) << 4);
@@ -236,7 +242,7 @@ __global__ __launch_bounds__(kThreads, 2) void attention_kernel(AttnArgs a) {
         for (int et = 0; et < 2; ++et) {
           const int cst = kt2 * 4096 + s2 * 2048;
           const int off0 = (et == 0 ? voff : voffx) + cst;
-          const int off1 = (et == 0 ? voffx : voff) + cst + 1024;
+          const int off1 = (off0 ^ 16) + 1024;          // keys + 8: swizzle bit 0 flips (see swz)
           const bf16x4 va = tr_read(v_hi + off0), vb = tr_read(v_hi + off1);
           const bf16x8 vh = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
           bf16x8 vl;

@@ -37,7 +37,13 @@ struct BwdArgs {
   int B, H, S; float qscale;
 };
 
-__device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
+// Chunk swizzle of a [rows][64 x 16-bit] LDS image (128-byte rows, eight 16-byte chunks) that serves BOTH kinds of read: chunk ^ swz(row) with swz = the three
+// bits of row >> 1 with bits 0 and 2 exchanged.  ds_read_b128 of a 32x32x16 operand (16 distinct rows per 16-lane group, one chunk column) needs swz to be a
+// bijection of (row >> 1) & 7 over those rows -- any bit permutation is; ds_read_b64_tr_b16 (a 32-lane half takes four consecutive rows x four chunks) needs rows
+// r and r + 2 (256 bytes apart: the same banks) in different 64-byte halves of their rows, i.e. bit 2 of the swizzle must follow bit 0 of row >> 1.  With the
+// plain (row >> 1) & 7 used until round 3 every transposed read was a 2-way bank conflict (SQ_LDS_BANK_CONFLICT = 24 % of the f16f8 kernel's LDS-active cycles).
+// Consequences for the offsets below: rows + 8 flip bit 2 of row >> 1 = bit 0 of the swizzle (byte ^ 16), rows + 16 / + 32 change nothing.
+__device__ __forceinline__ int swz(int row) { const int x = (row >> 1) & 7; return (x & 2) | ((x & 1) << 2) | (x >> 2); }
 __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) { glds16_asm(gsrc, lds_wave_base); }   // common.h: invisible to hipcc's vmcnt bookkeeping
 __device__ __forceinline__ bf16x4 tr_read(const char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)p);
@@ -97,10 +103,10 @@ __device__ __forceinline__ void trT_times_acc(f32x16 (&out)[2], const char* t_hi
     }
 #pragma unroll
     for (int et = 0; et < 2; ++et) {
-      // block offsets as in attention.hip: dim-tile et toggles byte bit 6, the +8-row block adds 1024 and toggles it back
+      // block offsets as in attention.hip: dim-tile et toggles byte bit 6, the +8-row block adds 1024 and flips byte bit 4
       const int cst = sub * 4096 + s * 2048;
       const int off0 = (et == 0 ? toff : toffx) + cst;
-      const int off1 = (et == 0 ? toffx : toff) + cst + 1024;
+      const int off1 = (off0 ^ 16) + 1024;              // rows + 8: swizzle bit 0 flips (see swz)
       const bf16x4 va = tr_read(t_hi + off0), vb = tr_read(t_hi + off1);
       const bf16x8 th = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
       if (TERMS == 3) {

@@ -41,7 +41,12 @@ struct Attn8Args {
   char* o_ilv;                                   // ... or the same activation as interleaved lines (common.h Act::ilv), when set
 };
 
-__device__ __forceinline__ int swz16(int row) { return (row >> 1) & 7; }        // fp16 planes: 128-byte rows, 8 chunks
+__device__ __forceinline__ int swz16(int row) { return (row >> 1) & 7; }        // K fp16 plane: 128-byte rows, 8 chunks, read by ds_read_b128 (32 distinct rows per chunk column)
+// V fp16 plane, read by ds_read_b64_tr_b16: a 32-lane half takes FOUR consecutive keys x four 16-byte chunks (8 bytes per lane).  Rows r and r + 2 are 256 bytes apart
+// = the same banks, so they must sit in different 64-byte halves of their rows: chunk ^ 4 for the odd row pairs.  (With swz16 on this plane -- the XOR of rows 2, 3
+// is 1, which stays inside chunks 0..3 -- every transposed read was a 2-way bank conflict: SQ_LDS_BANK_CONFLICT = 24 % of the LDS-active cycles of the round-3
+// kernel, profiles/r03_attention_shapes.txt; 16 of a tile's 32 LDS reads.)
+__device__ __forceinline__ int swz_v16(int row) { return ((row >> 1) & 1) << 2; }
 __device__ __forceinline__ int swz_k8(int row) { return (row >> 2) & 3; }       // K8 planes: 64-byte rows read by ds_read_b128
 __device__ __forceinline__ int swz_v8(int row) { return ((row >> 3) & 1) << 1; }   // V8 planes: rows k and k + 8 land in different 32-byte halves
 
@@ -67,9 +72,10 @@ __device__ __forceinline__ void stage_kv(const Attn8Args& a, int64_t head_off, i
       const int p = grp * 64 + lane;
       const int row = p >> 3;
       const unsigned off = (unsigned)(min(row, last) * 64 + (((p & 7) ^ swz16(row)) << 3));
+      const unsigned offv16 = (unsigned)(min(row, last) * 64 + (((p & 7) ^ swz_v16(row)) << 3));
       char* dst = stage + grp * 1024;
       glds16(k16 + off, dst + OFF_K16);
-      glds16(v16 + off, dst + OFF_V16);
+      glds16(v16 + offv16, dst + OFF_V16);
     }
   }
 #pragma unroll
@@ -153,7 +159,7 @@ __global__ __launch_bounds__(64 * NW, (QT == 1 && NW == 6) ? 3 : 2) void attenti
   for (int c = 0; c < 2; ++c) k8off[c] = ql * 64 + (((2 * half + c) ^ swz_k8(ql)) << 4);
   const int g = lane >> 4, li = lane & 15, qq = li >> 2, pp = li & 3;
   const int vkey = 4 * (g >> 1) + qq;
-  const int voff = vkey * 128 + (((2 * (g & 1) + (pp >> 1)) ^ swz16(vkey)) << 4) + 8 * (pp & 1);
+  const int voff = vkey * 128 + (((2 * (g & 1) + (pp >> 1)) ^ swz_v16(vkey)) << 4) + 8 * (pp & 1);
   const int voffx = voff ^ 64;
   const int tq = li >> 1, tp = li & 1;
   const int v8key = 8 * (tq >> 2) + (tq & 3) + 4 * (g >> 1);
@@ -247,7 +253,7 @@ __global__ __launch_bounds__(64 * NW, (QT == 1 && NW == 6) ? 3 : 2) void attenti
         for (int et = 0; et < 2; ++et) {
           const int cst = kt2 * 4096 + s2 * 2048;
           const int off0 = (et == 0 ? voff : voffx) + cst;
-          const int off1 = (et == 0 ? voffx : voff) + cst + 1024;
+          const int off1 = (et == 0 ? voff : voffx) + cst + 1024;     // keys + 8: swz_v16 repeats every 4 rows, so the same lane offset (under swz16 it was the other one)
           const bf16x4 va = tr_read16(cur + OFF_V16 + off0), vb = tr_read16(cur + OFF_V16 + off1);
           const bf16x8 vh = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
 #pragma unroll
@@ -326,7 +332,8 @@ constexpr int K3_SLOT = PL16 + 2 * PL8, V3_SLOT = PL16, K3_O8 = PL16, K3_OL8 = P
 // Loop-invariant for every tile but the last one of a sequence whose length is not a multiple of 64.
 template <int NW>
 struct KvLaneOff {
-  unsigned o16[8 / NW];      // fp16 planes (K and V share the swizzle)
+  unsigned o16[8 / NW];      // K fp16 plane
+  unsigned o16v[8 / NW];     // V fp16 plane (its own swizzle: swz_v16)
   unsigned o8k, o8v;         // e4m3 planes: K (ds_read_b128 swizzle) and V (transposing-read swizzle)
 };
 template <int NW>
@@ -336,6 +343,7 @@ __device__ __forceinline__ KvLaneOff<NW> kv_lane_off(int last, int wave, int lan
   for (int i = 0; i < 8 / NW; ++i) {
     const int p = (i * NW + wave) * 64 + lane, row = p >> 3;
     o.o16[i] = (unsigned)(min(row, last) * 64 + (((p & 7) ^ swz16(row)) << 3)) * 2u;
+    o.o16v[i] = (unsigned)(min(row, last) * 64 + (((p & 7) ^ swz_v16(row)) << 3)) * 2u;
   }
   const int p = (wave & 3) * 64 + lane, row = p >> 2;
   o.o8k = (unsigned)(min(row, last) * 64 + (((p & 3) ^ swz_k8(row)) << 4));
@@ -352,7 +360,7 @@ __device__ __forceinline__ void stage_kv1(const Attn8Args& a, int64_t head_off, 
   const uint8_t* pl8 = (ISK ? a.kl8 : a.vl8) + tile_off;
   constexpr int O16 = RING3 ? 0 : (ISK ? OFF_K16 : OFF_V16), O8 = RING3 ? K3_O8 : (ISK ? OFF_K8 : OFF_V8), OL8 = RING3 ? K3_OL8 : (ISK ? OFF_KL8 : OFF_VL8);
 #pragma unroll
-  for (int i = 0; i < 8 / NW; ++i) glds16_asm_sbase(p16, lo.o16[i], stage + O16 + (i * NW + wave) * 1024);
+  for (int i = 0; i < 8 / NW; ++i) glds16_asm_sbase(p16, ISK ? lo.o16[i] : lo.o16v[i], stage + O16 + (i * NW + wave) * 1024);
   if constexpr (!W8) return;          // fp16-only operand (V of the single-product P V): no e4m3 planes to stage
   const int grp = wave & 3;
   const unsigned off = ISK ? lo.o8k : lo.o8v;
@@ -403,7 +411,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f16f8_pipe_kernel(Attn8A
   for (int c = 0; c < 2; ++c) k8off[c] = ql * 64 + (((2 * half + c) ^ swz_k8(ql)) << 4);
   const int g = lane >> 4, li = lane & 15, qq = li >> 2, pp = li & 3;
   const int vkey = 4 * (g >> 1) + qq;
-  const int voff = vkey * 128 + (((2 * (g & 1) + (pp >> 1)) ^ swz16(vkey)) << 4) + 8 * (pp & 1);
+  const int voff = vkey * 128 + (((2 * (g & 1) + (pp >> 1)) ^ swz_v16(vkey)) << 4) + 8 * (pp & 1);
   const int voffx = voff ^ 64;
   const int tq = li >> 1, tp = li & 1;
   const int v8key = 8 * (tq >> 2) + (tq & 3) + 4 * (g >> 1);
@@ -465,7 +473,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f16f8_pipe_kernel(Attn8A
     } else if constexpr (SLOT < 20) {
       constexpr int I = SLOT - 12, kt2 = I >> 2, s2 = (I >> 1) & 1, et = I & 1;
       constexpr int cst = kt2 * 4096 + s2 * 2048;
-      const unsigned a0 = (et == 0 ? ra.v0 : ra.v1) + cst, a1 = (et == 0 ? ra.v1 : ra.v0) + cst + 1024;
+      const unsigned a0 = (et == 0 ? ra.v0 : ra.v1) + cst, a1 = a0 + 1024;     // keys + 8: swz_v16 repeats every 4 rows, so the same lane offset
       const i32x2 va = __builtin_bit_cast(i32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(uintptr_t)a0));
       const i32x2 vb2 = __builtin_bit_cast(i32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(uintptr_t)a1));
       f[0] = va[0]; f[1] = va[1]; f[2] = vb2[0]; f[3] = vb2[1];

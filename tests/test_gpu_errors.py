@@ -25,8 +25,10 @@ def test_create_rejects_unsupported_configs():
     assert rc == -1 and b"d_model" in L.awt_last_error()
     rc, _ = _create(wts.EncoderConfig(128, 2, 4, 512, 80, 1500, "hd32"))        # head_dim 32
     assert rc == -1 and b"head_dim" in L.awt_last_error()
-    rc, _ = _create(wts.config("mini"), terms=2)
+    rc, _ = _create(wts.config("mini"), terms=7)
     assert rc == -1 and b"mfma_terms" in L.awt_last_error()
+    rc, _ = _create(wts.config("mini"), terms=2, r=8, alpha=16.0, targets=_lib.LORA_BITS["fc1"], training=1)   # the single-fp16 measurement mode is inference-only too
+    assert rc == -1 and b"mfma_terms must be 1 or 3" in L.awt_last_error()
     rc, _ = _create(wts.config("mini"), terms=5, r=8, alpha=16.0, targets=_lib.LORA_BITS["fc1"], training=1)   # f16f8 is inference-only
     assert rc == -1 and b"mfma_terms must be 1 or 3" in L.awt_last_error()
     rc, _ = _create(wts.config("mini"), training=1)                                                              # nothing to train

@@ -20,7 +20,13 @@ for tag in tags:
             shutil.copy(p, os.path.join(ROOT, "profiles", "%s_%s_%s%s" % (rnd, base, suffix, ext)))
     t = os.path.join(src, "traffic.json")
     if os.path.exists(t):
-        entries.append(json.load(open(t)))
+        e = json.load(open(t))
+        if e.get("backward_precision"):          # a fine-tune-step profile: its own file, read by bench.py --workload finetune
+            json.dump({"note": "HBM / fabric traffic per launch of the fine-tune step (tools/profile_round.sh <tag> <prec> <wts> finetune); FETCH_SIZE x2 (gfx950)",
+                       "entries": [e]}, open(os.path.join(ROOT, "profiles", "traffic_finetune.json"), "w"), indent=1)
+            print("profiles/traffic_finetune.json:", e["build"], e["backward_precision"])
+        else:
+            entries.append(e)
 if entries:
     json.dump({"note": "HBM / fabric traffic per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/profile_round.sh); FETCH_SIZE x2 per the gfx950 "
                        "correction of MI355X_MICROARCH.md; bench.py attaches the entry whose build / precision / weights match the running library",

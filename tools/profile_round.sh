@@ -1,22 +1,32 @@
 #!/bin/bash
 # Round profile of the default bench workload: kernel-trace stats + HBM traffic counters (separate PMC passes).
-# Usage (GPU box): bash tools/profile_round.sh <tag> <precision> <weights: fp32 | fp16>
+# Usage (GPU box): bash tools/profile_round.sh <tag> <precision> <weights: fp32 | fp16> [encode | finetune]
+# finetune: the fine-tune step (BASELINE configs[2], library-default backward): kernel-trace stats + the FETCH_SIZE / WRITE_SIZE passes only -> traffic.json
+# with "backward_precision", which tools/collect_profiles.py merges into profiles/traffic_finetune.json (bench.py --workload finetune attaches it)
 # (bench.py starts no helper process of any kind under a profiler: its power sampler is a thread and stays off when rocprofv3's preload is present)
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
 tag=${1:-r03}
 prec=${2:-f16f8}
 wts=${3:-fp32}
+wl=${4:-encode}
+export AWT_PROFILE_WORKLOAD=$wl
 out=gpurun_out/prof_$tag; rm -rf $out; mkdir -p $out
-args="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fast-mode --no-power --precision $prec --weights $wts"
+if [ "$wl" = finetune ]; then
+  common="--workload finetune --no-cpu-baseline --precision $prec --backward-precision bf16x3"
+else
+  common="--no-cpu-baseline --no-fast-mode --no-power --no-configs --precision $prec --weights $wts"
+fi
+args="bench.py --steps 3 --warmup 1 $common"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $args > $out/trace.log 2>&1 || { echo "kernel-trace pass failed"; exit 1; }
 echo "pass trace done"
 pmc_pass() {   # <dir> <counters...>: one --pmc pass of a 1-step bench; a failed pass ends the script (no further GPU step after a failure)
   local d=$1; shift
-  timeout -k 10 240 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $out/$d -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-fast-mode --no-power --precision $prec --weights $wts > $out/$d.log 2>&1 || { echo "pass $d failed"; tail -3 $out/$d.log | cut -c1-300; exit 1; }
+  timeout -k 10 240 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $out/$d -- python3 bench.py --steps 1 --warmup 1 $common > $out/$d.log 2>&1 || { echo "pass $d failed"; tail -3 $out/$d.log | cut -c1-300; exit 1; }
   echo "pass $d done"
 }
 pmc_pass pmc_FETCH_SIZE FETCH_SIZE
 pmc_pass pmc_WRITE_SIZE WRITE_SIZE
+if [ "$wl" != finetune ]; then
 # MFMA utilisation and effective clock (own pass; SQ + GRBM slots)
 pmc_pass pmc_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE
 # Fabric side of the L2 (own passes): average L2 -> fabric read latency, cycles stalled for DRAM credits, L2 hit rate.  rocprofv3 on gfx950 exposes no
@@ -26,6 +36,7 @@ pmc_pass pmc_FABRIC_lat TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_LEVEL_sum
 pmc_pass pmc_FABRIC_dram TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum
 pmc_pass pmc_L2 TCC_HIT_sum TCC_MISS_sum
 pmc_pass pmc_L2cyc TCC_CYCLE_sum
+fi
 python3 - $out $tag $prec $wts <<'PY3'
 import csv, glob, json, sys, collections
 out, tag = sys.argv[1], sys.argv[2]
@@ -116,7 +127,10 @@ for k, d in res.items():
     summary[k] = {"launches_counted": n, "fetch_bytes_per_launch_corrected": fetch_kb * 1024 * 2 / max(n, 1),
                   "write_bytes_per_launch": write_kb * 1024 / max(n, 1),
                   "hbm_bytes_per_launch": (fetch_kb * 2 + write_kb) * 1024 / max(n, 1)}
-json.dump({"tag": tag, "build": bench.source_hash(), "precision": sys.argv[3], "weights": sys.argv[4], "workload": "bench.py default (Whisper-small, parity, B=64, %s, %s weights)" % (sys.argv[3], sys.argv[4]), "per_kernel": summary,
+import os
+wl = os.environ.get("AWT_PROFILE_WORKLOAD", "encode")
+json.dump({"tag": tag, "build": bench.source_hash(), "precision": sys.argv[3], "weights": sys.argv[4], "backward_precision": sys.argv[3] if wl == "finetune" else None,
+           "workload": ("bench.py --workload finetune (Whisper-small + LoRA r=8, B=64, %s, library-default backward)" % sys.argv[3]) if wl == "finetune" else "bench.py default (Whisper-small, parity, B=64, %s, %s weights)" % (sys.argv[3], sys.argv[4]), "per_kernel": summary,
            "note": "FETCH_SIZE x2 per the gfx950 correction; counters from separate --pmc passes"}, open(f"{out}/traffic.json", "w"), indent=1)
 print(json.dumps(summary, indent=1))
 PY
