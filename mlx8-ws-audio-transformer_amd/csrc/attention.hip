@@ -169,14 +169,10 @@ __global__ __launch_bounds__(kThreads, 2) void attention_kernel(AttnArgs a) {
         if (TERMS == 3) kl = *reinterpret_cast<const bf16x8*>(k_lo + off);
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
-#ifdef AWT_DIAG_ATTN_NO_CROSS   // timing-only: one product per fragment pair, lo operands still loaded / computed
-          if (TERMS == 3) asm volatile("" ::"v"(kl), "v"(qlo[t][ks]));
-#else
           if (TERMS == 3) {
             sacc[t][kt2] = mfma32<F16>(kh, qlo[t][ks], sacc[t][kt2]);
             sacc[t][kt2] = mfma32<F16>(kl, qh[t][ks], sacc[t][kt2]);
           }
-#endif
           sacc[t][kt2] = mfma32<F16>(kh, qh[t][ks], sacc[t][kt2]);
         }
       }
@@ -205,11 +201,7 @@ __global__ __launch_bounds__(kThreads, 2) void attention_kernel(AttnArgs a) {
       for (int kt2 = 0; kt2 < NSUB; ++kt2)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-#ifdef AWT_DIAG_ATTN_NO_EXP   // timing-only
-          const float pv = sacc[t][kt2][r] - m_new;
-#else
           const float pv = __builtin_amdgcn_exp2f(sacc[t][kt2][r] - m_new);
-#endif
           sacc[t][kt2][r] = pv;
           psum += pv;
         }
@@ -252,14 +244,10 @@ __global__ __launch_bounds__(kThreads, 2) void attention_kernel(AttnArgs a) {
           }
 #pragma unroll
           for (int t = 0; t < QT; ++t) {
-#ifdef AWT_DIAG_ATTN_NO_CROSS
-            if (TERMS == 3) asm volatile("" ::"v"(vl), "v"(pl[t]));
-#else
             if (TERMS == 3) {
               oacc[t][et] = mfma32<F16>(vh, pl[t], oacc[t][et]);
               oacc[t][et] = mfma32<F16>(vl, ph[t], oacc[t][et]);
             }
-#endif
             oacc[t][et] = mfma32<F16>(vh, ph[t], oacc[t][et]);
           }
         }

@@ -534,7 +534,6 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f16f8_pipe_kernel(Attn8A
     constexpr bool LAST = decltype(last_t)::value, TAIL = decltype(tail_t)::value;
     constexpr int FIRST = LAST ? 12 : 0;                  // the last tile has no next scores to compute
     const RdAddr ra = rd_addr(kslot(kt + 1), vslot(kt));   // K(kt + 1) for the next scores, V(kt) for this tile's output
-#ifndef AWT_DIAG8_NO_STAGE   // AWT_DIAG8_*: timing-only builds (tools/build_attn8_variants.sh), wrong results, never shipped
     if constexpr (!LAST) {
       if constexpr (RING3) {                              // K(kt + 3) takes K(kt)'s slot, V(kt + 2) takes V(kt - 1)'s
         if (kt + 3 < ntiles) stage_kv1<NW, true, true, true>(a, head_off, kt + 3, kslot(kt), wave, lane_off(kt + 3));
@@ -544,7 +543,6 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f16f8_pipe_kernel(Attn8A
         stage_kv1<NW, false, PV8>(a, head_off, kt + 1, vslot(kt + 1), wave, lane_off(kt + 1));
       }
     }
-#endif
     bf16x8 p16[4];
     i32x8 p8, pl8;
     float tmax = -1.0e30f, m_new, alpha, psum = 0.f;
@@ -570,13 +568,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f16f8_pipe_kernel(Attn8A
         constexpr int e = C - 2, kt2 = e >> 2, r4 = e & 3;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-#if defined(AWT_DIAG8_NO_SUB)
-          const float pv = __builtin_amdgcn_exp2f(sc[kt2][4 * r4 + j]);
-#elif defined(AWT_DIAG8_NO_EXP)
-          const float pv = sc[kt2][4 * r4 + j] - m_new;
-#else
           const float pv = __builtin_amdgcn_exp2f(sc[kt2][4 * r4 + j] - m_new);
-#endif
           sc[kt2][4 * r4 + j] = pv;
           psum += pv;
           p16[2 * kt2 + (r4 >> 1)][4 * (r4 & 1) + j] = (short)f32_to_f16(pv);
@@ -585,9 +577,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f16f8_pipe_kernel(Attn8A
         constexpr int et = C - 10;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-#ifndef AWT_DIAG8_NO_SUB
           oacc[et][r] *= alpha;
-#endif
         }
         if constexpr (et == 1) l_run = l_run * alpha + psum;
       } else if constexpr (C < 20 && PV8) {        // four accumulator registers -> one dword of each e4m3 operand
@@ -627,7 +617,6 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f16f8_pipe_kernel(Attn8A
         __builtin_amdgcn_sched_barrier(0);
       }(), ...);
     }(std::make_integer_sequence<int, NSLOT - FIRST>{});
-#ifndef AWT_DIAG8_NO_DMAWAIT
     if constexpr (RING3 && !LAST) {
       // only the loads of the PREVIOUS iteration have to have landed: this iteration issued NK (fp16 groups + e4m3 groups) K and NV V
       // LDS-DMA instructions per wave (fewer near the end of the key range)
@@ -638,7 +627,6 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f16f8_pipe_kernel(Attn8A
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-#endif
     __syncthreads();
   };
   // tiles in pairs so that the two score buffers swap roles without register copies
