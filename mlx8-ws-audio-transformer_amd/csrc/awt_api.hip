@@ -55,6 +55,11 @@ extern "C" int awt_tuning_set(const char* key, int value) {
     awt_gemm_set_pp_mode(value);
     return AWT_OK;
   }
+  if (!strcmp(key, "gemm_mfma16")) {
+    AWT_REQUIRE(value == 0 || value == 1, AWT_ERR_INVALID, "tuning_set: gemm_mfma16 must be 1 (default: the f16f8 GEMM's 16 x 16 MFMA form where it applies) or 0 (32 x 32 only)");
+    awt_gemm_set_mfma16(value);
+    return AWT_OK;
+  }
   if (!strcmp(key, "attn_shape")) {
     AWT_REQUIRE(value >= 0 && value <= 9, AWT_ERR_INVALID, "tuning_set: attn_shape must be 0 (auto) or 1 .. 9");
     awt_attn_force_shape(value);
@@ -167,6 +172,7 @@ struct Planes {  // a weight matrix as operand planes owned by the library: hi (
   // PREC_F16F8 inference: one device flag per separately uploaded row block (q | k | v): "a weight of this block is not exactly fp16";
   // exact16 = no flag set = the lo8 image is all zero and the GEMM drops that cross term (gemm.hip, WX)
   int* d_inexact = nullptr; bool exact16 = false;
+  bf16_t* s16 = nullptr; uint8_t* s8 = nullptr;   // f16f8: the 16-row fragment copies the 16 x 16 MFMA form of the GEMM reads (w_frag_index / w8s_index; common.h)
   char* pp = nullptr;   // PREC_F16F8 inference: the same matrix in the packed region image of the ping-pong GEMM (gemm_pp.h), N % 256 == 0 only
 };
 struct Linear {
@@ -227,7 +233,11 @@ int alloc_planes(awt_encoder* e, Planes* pl, int64_t rows, int64_t ld) {
   pl->rows = rows; pl->ld = ld;
   int rc = dev_alloc(e, (void**)&pl->hi, (size_t)rows * ld * 2); if (rc) return rc;
   if (e->planes == 2) { rc = dev_alloc(e, (void**)&pl->lo, (size_t)rows * ld * 2); if (rc) return rc; }
-  if (e->prec == PREC_F16F8) pl->x8 = (uint8_t*)pl->lo + (size_t)rows * ld;
+  if (e->prec == PREC_F16F8) {
+    pl->x8 = (uint8_t*)pl->lo + (size_t)rows * ld;
+    rc = dev_alloc(e, (void**)&pl->s16, (size_t)rows * ld * 2); if (rc) return rc;
+    rc = dev_alloc(e, (void**)&pl->s8, (size_t)rows * ld * 2); if (rc) return rc;
+  }
   return AWT_OK;
 }
 int alloc_planes_f8(awt_encoder* e, Planes* pl, int64_t rows, int64_t ld) {   // fp16 plane + the two e4m3 planes, whatever the forward precision
@@ -235,6 +245,8 @@ int alloc_planes_f8(awt_encoder* e, Planes* pl, int64_t rows, int64_t ld) {   //
   int rc = dev_alloc(e, (void**)&pl->hi, (size_t)rows * ld * 2); if (rc) return rc;
   rc = dev_alloc(e, (void**)&pl->lo, (size_t)rows * ld * 2); if (rc) return rc;
   pl->x8 = (uint8_t*)pl->lo + (size_t)rows * ld;
+  rc = dev_alloc(e, (void**)&pl->s16, (size_t)rows * ld * 2); if (rc) return rc;
+  rc = dev_alloc(e, (void**)&pl->s8, (size_t)rows * ld * 2); if (rc) return rc;
   return AWT_OK;
 }
 int alloc_linear(awt_encoder* e, Linear* l, int N, int K) {
@@ -312,6 +324,7 @@ GemmSeg seg_plain(const Act& a, int64_t lda, const Planes& w, int64_t wcol, int 
   s.rows_out = M; s.rows_in = M; s.row_mul = 1; s.row_add = 0;
   s.w_exact16 = w.exact16 ? 1 : 0;
   s.a_ilv = a.ilv; s.w_pp = w.pp;
+  s.ws16 = w.s16; s.ws8 = w.s8;
   return s;
 }
 GemmSeg seg_plain(const bf16_t* a_hi, const bf16_t* a_lo, int64_t lda, const Planes& w, int64_t wcol, int K, int M) {   // bf16 planes (backward pass)
@@ -627,7 +640,7 @@ extern "C" int awt_encoder_set_weight(awt_encoder* e, const char* name, const fl
   const int d = c.d_model, f = c.ffn_dim, r = c.lora_rank;
   int rc = AWT_ERR_INVALID;
   auto pack = [&](const Planes& pl, int N, int C, int taps, int row_off, int col_off) {
-    return launch_pack_weight(e->ctx, data, N, C, taps, pl.ld, row_off, col_off, 1.0f, pl.hi, pl.lo, pl.x8, e->prec, s);
+    return launch_pack_weight(e->ctx, data, N, C, taps, pl.ld, row_off, col_off, 1.0f, pl.hi, pl.lo, pl.x8, e->prec, s, nullptr, pl.s16, pl.s8);
   };
   std::string nm(name);
   if (nm == "conv1.weight") { rc = check_shape(name, shape, rank, {d, c.n_mels, 3}); if (!rc) rc = pack(e->conv1.w, d, c.n_mels, 3, 0, 0); }
@@ -660,7 +673,7 @@ extern "C" int awt_encoder_set_weight(awt_encoder* e, const char* name, const fl
           int* flag = pl.d_inexact + p.row_off / p.N;
           int host[4] = {0, 0, 0, 0};
           if (hipMemsetAsync(flag, 0, sizeof(int), s) != hipSuccess) rc = awt_fail(AWT_ERR_HIP, "set_weight: flag reset failed");
-          if (!rc) rc = launch_pack_weight(e->ctx, data, p.N, p.K, 1, pl.ld, p.row_off, 0, 1.0f, pl.hi, pl.lo, pl.x8, e->prec, s, flag);
+          if (!rc) rc = launch_pack_weight(e->ctx, data, p.N, p.K, 1, pl.ld, p.row_off, 0, 1.0f, pl.hi, pl.lo, pl.x8, e->prec, s, flag, pl.s16, pl.s8);
           if (!rc && (hipMemcpyAsync(host, pl.d_inexact, sizeof(host), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess))
             rc = awt_fail(AWT_ERR_HIP, "set_weight: flag read-back failed");
           if (!rc) pl.exact16 = !(host[0] | host[1] | host[2] | host[3]);
@@ -670,8 +683,8 @@ extern "C" int awt_encoder_set_weight(awt_encoder* e, const char* name, const fl
           rc = launch_pack_weight_t(e->ctx, data, p.N, p.K, p.wT->ld, 0, p.row_off, 1.0f, p.wT->hi, p.wT->lo, s);
         if (!rc && e->mlp_f8 && p.wT8) {   // the same W^T [K, N] in the f16f8 weight format: transposed into the scratch matrix, then packed like a forward weight
           rc = launch_transpose_f32(e->ctx, data, p.N, p.K, e->wt_tmp, s);
-          if (!rc) rc = launch_pack_weight(e->ctx, e->wt_tmp, p.K, p.N, 1, p.wT8->ld, 0, 0, 1.0f, p.wT8->hi, p.wT8->lo, p.wT8->x8, PREC_F16F8, s);
-          if (!rc) rc = launch_pack_weight(e->ctx, data, p.N, p.K, 1, p.w8->ld, 0, 0, 1.0f, p.w8->hi, p.w8->lo, p.w8->x8, PREC_F16F8, s);
+          if (!rc) rc = launch_pack_weight(e->ctx, e->wt_tmp, p.K, p.N, 1, p.wT8->ld, 0, 0, 1.0f, p.wT8->hi, p.wT8->lo, p.wT8->x8, PREC_F16F8, s, nullptr, p.wT8->s16, p.wT8->s8);
+          if (!rc) rc = launch_pack_weight(e->ctx, data, p.N, p.K, 1, p.w8->ld, 0, 0, 1.0f, p.w8->hi, p.w8->lo, p.w8->x8, PREC_F16F8, s, nullptr, p.w8->s16, p.w8->s8);
         }
       }
       else if (rs == key + ".bias") {
@@ -786,7 +799,7 @@ extern "C" int awt_audio_encode(awt_encoder* e, const void* pcm, int pcm_is_i16,
 
 // ------------------------------------------------------------------------------------------------ single operators
 extern "C" size_t awt_op_linear_workspace_bytes(int M, int N, int K) {
-  return 2 * align_up((size_t)M * K * 2) + 2 * align_up((size_t)N * K * 2) + 256;     // + a flag word (fp16-exact weights)
+  return 2 * align_up((size_t)M * K * 2) + 4 * align_up((size_t)N * K * 2) + 256;     // x planes, w planes, a flag word (fp16-exact weights), the 16-row w copies (f16f8)
 }
 extern "C" int awt_op_linear(awt_ctx* c, const float* x, const float* w, const float* bias, float* y, int M, int N, int K,
                              int terms, void* workspace, size_t ws_bytes, void* stream) {
@@ -833,7 +846,8 @@ extern "C" int awt_op_linear(awt_ctx* c, const float* x, const float* w, const f
     int* flag = (int*)((char*)wl + align_up((size_t)N * K * 2));      // word of the workspace's 256-byte tail
     int host = 1;
     if (hipMemsetAsync(flag, 0, sizeof(int), s) != hipSuccess) return awt_fail(AWT_ERR_HIP, "op_linear: flag reset failed");
-    rc = launch_pack_weight(c, w, N, K, 1, K, 0, 0, 1.0f, wh, wl, pw.x8, terms, s, flag); if (rc) return rc;
+    if (terms == PREC_F16F8) { pw.s16 = (bf16_t*)((char*)flag + 256); pw.s8 = (uint8_t*)pw.s16 + align_up((size_t)N * K * 2); }
+    rc = launch_pack_weight(c, w, N, K, 1, K, 0, 0, 1.0f, wh, wl, pw.x8, terms, s, flag, pw.s16, pw.s8); if (rc) return rc;
     if (hipMemcpyAsync(&host, flag, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
       return awt_fail(AWT_ERR_HIP, "op_linear: flag read-back failed");
     pw.exact16 = host == 0;

@@ -216,6 +216,14 @@ __host__ __device__ __forceinline__ int64_t w8_index(int n, int k, int ktiles64)
   return (((int64_t)nt * ktiles64 + kt) * 64 + (h * 32 + r)) * 32 + b;
 }
 
+// The 16 x 16 MFMA form of the f16f8 GEMM (gemm_f8s_kernel) reads the fp16 plane in w_frag_index order (16-row n-tiles, fp16 values) and BOTH e4m3 planes from
+// one image in the operand order of v_mfma_scale_f32_16x16x128_f8f6f4: per (16-row n-tile, 64-deep K-tile) a 2 KB block, lane 16 kb + r holding the 32 bytes
+// lo8[16 nt + r][64 kt + 32 kb ..] for kb < 2 and hi8[16 nt + r][64 kt + 32 (kb - 2) ..] above (the activation operand carries hi8 | lo8 in the same block order)
+__host__ __device__ __forceinline__ int64_t w8s_index(int n, int k, int ktiles64, int is_hi8) {
+  const int nt = n >> 4, r = n & 15, kt = k >> 6, kb = ((k & 63) >> 5) + (is_hi8 ? 2 : 0), b = k & 31;
+  return (((int64_t)nt * ktiles64 + kt) * 64 + (kb * 16 + r)) * 32 + b;
+}
+
 // An activation matrix as MFMA operand planes: p16 (bf16 or fp16) + lo16 (split modes) or + hi8 / lo8 (f16f8).
 // ilv (PREC_F16F8 only, instead of the three planes): the INTERLEAVED-LINE image the ping-pong GEMM (gemm_pp.h) stages by whole cache
 // lines -- a dense [M][K] matrix, K % 32 == 0, as [M][K / 32] lines of 128 bytes = the 32 elements' fp16 | hi8 | lo8 (64 + 32 + 32 bytes),
@@ -312,6 +320,9 @@ struct GemmSeg {
   // ping-pong kernel (launch_gemm_pp, PREC_F16F8): the activation as interleaved lines (Act::ilv, row pitch lda * 4 bytes) and the weight matrix in
   // the packed region image of gemm_pp.h (launch_pack_weight_pp); both null = the segment is only for the kernels above
   const char* a_ilv; const char* w_pp;
+  // 16 x 16 MFMA form (gemm_f8s_kernel, PREC_F16F8): the same weight matrix as 16-row fragment-major copies -- fp16 in w_frag_index order, the two e4m3
+  // planes interleaved per (16-row n-tile, 64-deep K-tile) block in w8s_index order (gemm.hip); null = the 32 x 32 kernels
+  const bf16_t* ws16; const uint8_t* ws8;
   int K;                                                 // multiple of the kernel's BK
   // source row of output row m:  (m / rows_out) * rows_in + (m % rows_out) * row_mul + row_add ; rows outside
   // [0, rows_in) of their group read as zeros (the conv stem's padding).  Plain GEMM: rows_out = rows_in = M.
@@ -357,6 +368,7 @@ size_t gemm_pp_weight_bytes(int N, int K);          // packed image of an [N, K]
 int launch_pack_weight_pp(awt_ctx* c, const float* src, int N, int K, int row_off, char* dst, hipStream_t s);
 int awt_gemm_pp_mode();                             // tuning knob "gemm_pp": 0 off (default), 1 automatic, 2 wherever supported
 void awt_gemm_set_pp_mode(int v);
+void awt_gemm_set_mfma16(int v);                    // tuning knob "gemm_mfma16": 1 (default) = the 16 x 16 MFMA form of the f16f8 GEMM wherever its weight copies exist, 0 = off
 
 // out_f32 (the final layer_norm) or operand planes of precision `prec`
 int launch_layernorm(awt_ctx* c, const float* x, const float* gamma, const float* beta, int M, int d, float eps,
@@ -381,7 +393,8 @@ int launch_attention_f16f8(awt_ctx* c, const F8Planes& q, const F8Planes& k, con
 int launch_split_planes_f6(awt_ctx* c, const float* x, int M, int K, bf16_t* p16, uint8_t* hi6, uint8_t* lo6, hipStream_t s);
 int launch_pack_weight_f6(awt_ctx* c, const float* w, int N, int K, bf16_t* w16, uint8_t* hi6, uint8_t* lo6, hipStream_t s);
 int launch_pack_weight(awt_ctx* c, const float* src, int N, int C, int taps, int64_t ld, int row_off, int col_off, float scale,
-                       bf16_t* hi, bf16_t* lo, uint8_t* lo8, int prec, hipStream_t s, int* inexact = nullptr);   // inexact (PREC_F16F8, device int): set to 1 when a weight is not fp16-exact
+                       bf16_t* hi, bf16_t* lo, uint8_t* lo8, int prec, hipStream_t s, int* inexact = nullptr,    // inexact (PREC_F16F8, device int): set to 1 when a weight is not fp16-exact
+                       bf16_t* s16 = nullptr, uint8_t* s8 = nullptr);                                            // PREC_F16F8: also the 16-row copies (w_frag_index / w8s_index) when given
 // conv1 im2col: mel f32 [B, C, T] -> A [B*T, K_dst] bf16 hi/lo, k = dt * C + c reads mel[b, c, t + dt - 1]
 int launch_im2col_conv1(awt_ctx* c, const float* mel, int B, int C, int T, int K_dst, const Act& out, int prec, hipStream_t s);
 

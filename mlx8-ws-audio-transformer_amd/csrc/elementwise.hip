@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
 template <int PREC>
 __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ src, int N, int C, int taps, int64_t ld,
                                                           int row_off, int col_off, float scale, bf16_t* hi, bf16_t* lo, uint8_t* lo8,
-                                                          int* inexact) {
+                                                          int* inexact, bf16_t* s16, uint8_t* s8) {
   const int K = C * taps;
   bool any_inexact = false;       // PREC_F16F8: some weight is not exactly representable in fp16 (its lo8 image is non-zero)
   const int64_t total = (int64_t)N * K;
@@ -124,6 +124,11 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
       const int64_t o8 = w8_index(row_off + n, col_off + k, (int)(ld >> 6));
       reinterpret_cast<uint8_t*>(lo)[o8] = (uint8_t)(fp8x4<kF8Wgt>(v, 0.f, 0.f, 0.f) & 0xFF);
       lo8[o8] = (uint8_t)(fp8x4<kF8Wgt + kF8Lo>(v - f16_to_f32(h), 0.f, 0.f, 0.f) & 0xFF);
+      if (s16) {   // the 16-row copies of the 16 x 16 MFMA form (gemm_f8s_kernel)
+        s16[w_frag_index(row_off + n, col_off + k, (int)(ld >> 5))] = h;
+        s8[w8s_index(row_off + n, col_off + k, (int)(ld >> 6), 1)] = reinterpret_cast<uint8_t*>(lo)[o8];
+        s8[w8s_index(row_off + n, col_off + k, (int)(ld >> 6), 0)] = lo8[o8];
+      }
       any_inexact |= (v != f16_to_f32(h));
     } else {
       bf16_t h, l; split16<PREC == PREC_F16X3>(v, h, l);
@@ -501,14 +506,14 @@ int launch_pack_weight_pp(awt_ctx* c, const float* src, int N, int K, int row_of
 }
 
 int launch_pack_weight(awt_ctx* c, const float* src, int N, int C, int taps, int64_t ld, int row_off, int col_off, float scale,
-                       bf16_t* hi, bf16_t* lo, uint8_t* lo8, int prec, hipStream_t s, int* inexact) {
+                       bf16_t* hi, bf16_t* lo, uint8_t* lo8, int prec, hipStream_t s, int* inexact, bf16_t* s16, uint8_t* s8) {
   AWT_REQUIRE(src && hi && N > 0 && C > 0 && taps > 0 && ld >= col_off + (int64_t)C * taps && ld % 32 == 0, AWT_ERR_INVALID, "pack_weight: bad shape");
   AWT_REQUIRE(prec != PREC_F16F8 || (lo && lo8 && ld % 64 == 0), AWT_ERR_INVALID, "pack_weight: f16f8 needs both e4m3 planes and K a multiple of 64");
   const int64_t total = (int64_t)N * C * taps;
   int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
-  if (prec == PREC_F16F8) hipLaunchKernelGGL(pack_weight_kernel<PREC_F16F8>, dim3(grid), dim3(256), 0, s, src, N, C, taps, ld, row_off, col_off, scale, hi, lo, lo8, inexact);
-  else if (prec == PREC_F16X3 || prec == PREC_F16) hipLaunchKernelGGL(pack_weight_kernel<PREC_F16X3>, dim3(grid), dim3(256), 0, s, src, N, C, taps, ld, row_off, col_off, scale, hi, prec == PREC_F16 ? nullptr : lo, lo8, inexact);
-  else hipLaunchKernelGGL(pack_weight_kernel<PREC_BF16X3>, dim3(grid), dim3(256), 0, s, src, N, C, taps, ld, row_off, col_off, scale, hi, lo, lo8, inexact);
+  if (prec == PREC_F16F8) hipLaunchKernelGGL(pack_weight_kernel<PREC_F16F8>, dim3(grid), dim3(256), 0, s, src, N, C, taps, ld, row_off, col_off, scale, hi, lo, lo8, inexact, s8 ? s16 : nullptr, s8);
+  else if (prec == PREC_F16X3 || prec == PREC_F16) hipLaunchKernelGGL(pack_weight_kernel<PREC_F16X3>, dim3(grid), dim3(256), 0, s, src, N, C, taps, ld, row_off, col_off, scale, hi, prec == PREC_F16 ? nullptr : lo, lo8, inexact, nullptr, nullptr);
+  else hipLaunchKernelGGL(pack_weight_kernel<PREC_BF16X3>, dim3(grid), dim3(256), 0, s, src, N, C, taps, ld, row_off, col_off, scale, hi, lo, lo8, inexact, nullptr, nullptr);
   AWT_HIP_CHECK(hipGetLastError());
   return AWT_OK;
 }

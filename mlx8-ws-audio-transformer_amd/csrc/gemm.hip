@@ -529,13 +529,13 @@ __device__ __forceinline__ i32x8 cat8(bf16x8 lo, bf16x8 hi) {
 // The vector-memory operations a prefetching K-tile issues (for K-tile kt + 1), in program order -- vmcnt retires in this order, so every counted wait of the
 // K loop is "the operations issued after the one waited for":
 //     position 0 .. NDMA - 1                    the LDS-DMA pieces, DMA_PER_STEP of them ahead of each row tile's MFMAs of k-step 0
-//     position NDMA + ks TN + j  (ks < 4)       fp16 W fragment j of k-step ks into the register ring, issued behind k-step ks's last MFMAs
-//     position NDMA + 4 TN .. N - 1             the e4m3 W planes, issued behind the e4m3 part
+//     position NDMA + ks TN + j  (ks < KS)      fp16 W fragment j of k-step ks into the register ring, issued behind k-step ks's last MFMAs
+//     position NDMA + KS TN .. N - 1            the e4m3 W planes, issued behind the e4m3 part
 // A hand-written count that disagrees with this order waits for the wrong operation (garbage fragments, or -- during bring-up -- a load landing in registers
 // the epilogue had reused: a memory fault), so the counts are computed here and nowhere else.
-template <int TM, int TN, int NDMA, int NW8>
+template <int TM, int TN, int NDMA, int NW8, int KS = 4>
 struct F8IssueOrder {
-  static constexpr int NW16 = 4 * TN, N = NDMA + NW16 + NW8;
+  static constexpr int NW16 = KS * TN, N = NDMA + NW16 + NW8;
   static constexpr int DMA_PER_STEP = (NDMA + TM - 1) / TM;
   static constexpr int last_dma = NDMA - 1;
   static constexpr int last_w16(int ks) { return NDMA + ks * TN + TN - 1; }
@@ -551,10 +551,10 @@ struct F8IssueOrder {
   template <bool PF> static constexpr int w8_wait() { return younger(last_w8, PF ? issued_at_f8 : 0); }
   // at the K-tile barrier, after this K-tile's last operation was issued: only its DMA pieces must have landed (AWT_GEMM_WDEC) / also its fp16 fragments
   static constexpr int dma_wait_at_barrier() { return N - 1 - last_dma; }
-  static constexpr int w16_wait_at_barrier() { return N - 1 - last_w16(3); }
-  static_assert(w16_wait<true>(0) == 3 * TN + NW8 + DMA_PER_STEP && w16_wait<true>(3) == 3 * TN + NW8 + NDMA && w16_wait<false>(1) == 2 * TN + NW8, "w16 waits");
+  static constexpr int w16_wait_at_barrier() { return N - 1 - last_w16(KS - 1); }
+  static_assert(w16_wait<true>(0) == (KS - 1) * TN + NW8 + DMA_PER_STEP && w16_wait<true>(KS - 1) == (KS - 1) * TN + NW8 + NDMA && w16_wait<false>(1) == (KS - 2) * TN + NW8, "w16 waits");
   static_assert(w8_wait<true>() == NDMA + NW16 && w8_wait<false>() == 0 && dma_wait_at_barrier() == NW16 + NW8 && w16_wait_at_barrier() == NW8, "w8 / barrier waits");
-  static_assert(w16_wait<true>(3) <= 63, "vmcnt is a 6-bit count");
+  static_assert(w16_wait<true>(KS - 1) <= 63, "vmcnt is a 6-bit count");
 };
 
 // WX: every weight of the (single) K segment is exactly representable in fp16 (true of checkpoints stored in half precision), so its lo plane is
@@ -877,6 +877,298 @@ __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, CFG::WM * CFG::WN == 4 ? 2 
   };
   // wave-uniform: the whole block tile inside the matrix (every tile of the encoder's shapes; only a ragged last row panel takes the other path)
   if (m0 + BM <= g.M && n0 + BN <= g.out.n_valid) strips(std::true_type{}); else strips(std::false_type{});
+}
+
+// ------------------------------------------------------------------------------------------------ the same GEMM on 16 x 16 MFMAs
+// Under the package power limit the chip holds a higher clock on the 16 x 16 MFMA shapes than on the 32 x 32 ones at equal matrix-pipe cycles
+// (MI355X_MICROARCH.md "DVFS give-back" item 7; measured here on this kernel's own instruction mix with random operands, tools/mfma_power.hip,
+// profiles/r04_mfma_shape_mix.txt: 4.32 vs 5.08 us per round = 15 % less time for the identical arithmetic).  gemm_f8s_kernel is gemm_f8_kernel's 128 x 256
+// four-wave tile with every product issued as 16 x 16 instructions:
+//     a16 w16                  2 k-steps of v_mfma_f32_16x16x32_f16                       (16 cycles each)
+//     a8 wl8 + al8 w8          1 x v_mfma_scale_f32_16x16x128_f8f6f4: lane (row r, block kb) holds hi8[32 kb ..] for kb < 2 and lo8[32 (kb - 2) ..] above,
+//                              the weight operand lo8 | hi8 in the same block order -- both cross terms of the 64-deep K-tile in one instruction, and since
+//                              2^-Act 2^(-Wgt - 11) is the scale of BOTH (hi8 wlo8 and lo8 whi8) ONE E8M0 scale per operand serves all four blocks
+// = the same 256 matrix-pipe cycles per 32 x 32 x 64 of work, the same LDS images (A16 | A8 | Al8 by LDS-DMA) and bytes, the same K-loop skeleton (sixteen fp16
+// steps of 64 cycles with a four-entry fragment ring, eight e4m3 steps of 128 cycles, W fragments in a register ring reloaded a K-tile ahead, counted waits from
+// F8IssueOrder).  What changes is every fragment layout: 16-row A fragments (fp16: row lane & 15, chunk 4 ks + (lane >> 4); e4m3: plane (lane >> 5), chunks
+// 2 ((lane >> 4) & 1) + q, images swizzled by (row >> 3) & 1 instead of (row >> 2) & 3), weights from their 16-row fragment-major copies (fp16: w_frag_index;
+// e4m3: w8s_index, lo8 and hi8 interleaved per 2 KB block), and a 16 x 16 C layout (col = lane & 15, row = 4 (lane >> 4) + reg) into the epilogue's patch.
+template <int N> __device__ __forceinline__ void wait_vm(bf16x8& f0, bf16x8& f1, bf16x8& f2, bf16x8& f3) {
+  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3) : "n"(N) : "memory");
+}
+
+template <int EPI, bool MULTI>
+__global__ __launch_bounds__(256, 2) void gemm_f8s_kernel(GemmArgs g) {
+  constexpr int TM = 8, TN = 4, KS = 2;                                  // per wave: 8 x 4 tiles of 16 x 16; two 32-deep fp16 k-steps per K-tile
+  constexpr int BM = 128, BN = 256, BK = 64, NT = 256;
+  constexpr int PL16 = BM * BK * 2, PL8 = BM * BK, STAGE = PL16 + 2 * PL8;
+  constexpr int IT16 = PL16 / 16 / NT, IT8 = PL8 / 16 / NT;             // 4, 2 (+ 2)
+  constexpr int NDMA = IT16 + 2 * IT8, NW16 = KS * TN, NW8 = 2 * TN;
+  constexpr unsigned kInvalid = 0xFFFFFFFFu;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tid = wave * 64 + lane;
+
+  const int nwg = g.tiles_m * g.tiles_n;
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int qn = nwg >> 3, rn = nwg & 7;
+  const int tile = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + idx;
+  const int GM = g.gm;
+  int tm, tn;
+  {
+    const int grp = tile / (GM * g.tiles_n);
+    const int gm = min(GM, g.tiles_m - grp * GM);
+    const int within = tile - grp * GM * g.tiles_n;
+    tn = within / gm; tm = grp * GM + (within - tn * gm);
+  }
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int wc = wave;
+  const int r16 = lane & 15, kq = lane >> 4;
+
+  int ktiles = 0;
+  for (int s = 0; s < (MULTI ? g.nseg : 1); ++s) ktiles += g.seg[s].K / BK;
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){};
+
+  unsigned a16o[IT16], a8o[IT8];
+  const char *a16b, *a8b, *al8b;
+  const char *w16b[TN], *w8b[TN];
+  const unsigned wl16 = lane * 16, wl32 = lane * 32;
+  int si = 0, kk = 0, nk = 0;
+  auto open_segment = [&](int seg) {
+    si = seg; kk = 0;
+    const GemmSeg& sg = g.seg[seg];
+    nk = sg.K / BK;
+    const int mb = m0 < g.M ? m0 : g.M - 1;
+    const int grp0 = mb / sg.rows_out;
+    const int sr0 = (mb - grp0 * sg.rows_out) * sg.row_mul + sg.row_add;
+    const int64_t base_row = (int64_t)grp0 * sg.rows_in + (sr0 > 0 ? sr0 : 0);
+#pragma unroll
+    for (int it = 0; it < IT16; ++it) {
+      const int p = it * NT + tid, row = p >> 3, c = (p & 7) ^ ((row >> 1) & 7);
+      int m = m0 + row; m = m < g.M ? m : g.M - 1;
+      const int grp = m / sg.rows_out, r = m - grp * sg.rows_out;
+      const int sr = r * sg.row_mul + sg.row_add;
+      a16o[it] = (sr >= 0 && sr < sg.rows_in) ? (unsigned)((((int64_t)grp * sg.rows_in + sr - base_row) * sg.lda + c * 8) * 2) : kInvalid;
+    }
+#pragma unroll
+    for (int it = 0; it < IT8; ++it) {
+      const int p = it * NT + tid, row = p >> 2, c = (p & 3) ^ ((row >> 3) & 1);      // the 16-row fragment reads' swizzle (below)
+      int m = m0 + row; m = m < g.M ? m : g.M - 1;
+      const int grp = m / sg.rows_out, r = m - grp * sg.rows_out;
+      const int sr = r * sg.row_mul + sg.row_add;
+      a8o[it] = (sr >= 0 && sr < sg.rows_in) ? (unsigned)(((int64_t)grp * sg.rows_in + sr - base_row) * sg.lda + c * 16) : kInvalid;
+    }
+    a16b = (const char*)sg.a_hi + base_row * sg.lda * 2; a8b = (const char*)sg.a8 + base_row * sg.lda; al8b = (const char*)sg.al8 + base_row * sg.lda;
+    const int nt0 = (n0 >> 4) + wc * TN;
+    const int64_t w16_ts = (int64_t)sg.w_ksteps * 1024;               // bytes per 16-row n-tile of the fp16 copy: (K / 32) blocks of 1 KB
+    const int64_t w8_ts = (int64_t)(sg.w_ksteps / 2) * 2048;          // bytes per n-tile of the e4m3 copy: (K / 64) blocks of 2 KB (lo8 | hi8)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      w16b[j] = (const char*)sg.ws16 + (nt0 + j) * w16_ts + (int64_t)sg.w_k0 * 1024;
+      w8b[j] = (const char*)sg.ws8 + (nt0 + j) * w8_ts + (int64_t)(sg.w_k0 / 2) * 2048;
+    }
+  };
+  auto advance = [&]() {
+    if (kk + 1 < nk) {
+      ++kk;
+      a16b += BK * 2; a8b += BK; al8b += BK;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) { w16b[j] += KS * 1024; w8b[j] += 2048; }
+    } else if (MULTI && si + 1 < g.nseg) {
+      open_segment(si + 1);
+    }
+  };
+  auto dma = [&](auto op_t, char* stage) {
+    constexpr int OP = decltype(op_t)::value;
+    if constexpr (OP < IT16) {
+      const unsigned o = a16o[OP];
+      glds16(o != kInvalid ? (const void*)(a16b + o) : (const void*)g.zeros, stage + (OP * NT + wave * 64) * 16);
+    } else if constexpr (OP < IT16 + IT8) {
+      const unsigned o = a8o[OP - IT16];
+      glds16(o != kInvalid ? (const void*)(a8b + o) : (const void*)g.zeros, stage + PL16 + ((OP - IT16) * NT + wave * 64) * 16);
+    } else {
+      constexpr int P8 = OP - IT16 - IT8;
+      const unsigned o = a8o[P8];
+      glds16(o != kInvalid ? (const void*)(al8b + o) : (const void*)g.zeros, stage + PL16 + PL8 + (P8 * NT + wave * 64) * 16);
+    }
+  };
+
+  bf16x8 w16[KS][TN];             // fp16 B fragments of the K-tile's two k-steps
+  bf16x8 w8[TN][2];               // e4m3 operands (32 bytes = two 16-byte halves): lo8 blocks on lanes 0-31, hi8 blocks on lanes 32-63
+  auto load_w16 = [&](auto ks_t) {
+    constexpr int ks = decltype(ks_t)::value;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) w16[ks][j] = gload16<ks * 1024>(wl16, w16b[j]);
+  };
+  auto load_w8 = [&]() {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { w8[j][0] = gload16<0>(wl32, w8b[j]); w8[j][1] = gload16<16>(wl32, w8b[j]); }
+  };
+
+  open_segment(0);
+  [&]<int... O>(std::integer_sequence<int, O...>) { (dma(std::integral_constant<int, O>{}, smem), ...); }(std::make_integer_sequence<int, NDMA>{});
+  load_w16(std::integral_constant<int, 0>{}); load_w16(std::integral_constant<int, 1>{});
+  load_w8();
+  wait_vm<0>();
+  __builtin_amdgcn_s_barrier();
+
+  // A fragment addresses in the CURRENT stage (flipped per K-tile).  fp16 image: row r16 (+ 16 per row tile: immediate 2048), chunk (4 ks + kq) ^ ((row >> 1) & 7).
+  // e4m3 images: plane kq >> 1 (hi8 | lo8), row r16 (+ 16 per row tile: immediate 1024), chunk (2 (kq & 1) + q) ^ ((row >> 3) & 1): per 16-lane group of a
+  // ds_read_b128 the rows 0-3 | 12-15 at chunk c and 4-11 at chunk c + 2 (or the mirrored set) then cover all sixteen 16-byte slots of the 256-byte bank row.
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)(smem);
+  unsigned a16a[KS], a8a[2];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) a16a[ks] = lds0 + r16 * 128 + (((4 * ks + kq) ^ ((r16 >> 1) & 7)) << 4);
+#pragma unroll
+  for (int q = 0; q < 2; ++q) a8a[q] = lds0 + PL16 + (kq >> 1) * PL8 + r16 * 64 + (((2 * (kq & 1) + q) ^ ((r16 >> 3) & 1)) << 4);
+
+  constexpr int DMA_PER_STEP = (NDMA + TM - 1) / TM;
+  using ORD = F8IssueOrder<TM, TN, NDMA, NW8, KS>;
+  static_assert(ORD::DMA_PER_STEP == DMA_PER_STEP && ORD::NW16 == NW16, "issue-order table and kernel disagree");
+  auto ktile = [&](auto pf_t, int kt) {
+    constexpr bool PF = decltype(pf_t)::value;
+    char* nxt = smem + ((kt + 1) & 1) * STAGE;
+    if constexpr (PF) advance();
+    // ---- fp16 part: KS x TM steps of TN MFMAs (64 matrix-pipe cycles), fragments read AD steps ahead into a ring
+    constexpr int AD = MULTI ? 1 : 3;
+    bf16x8 af[AD + 1];
+    auto read_a16 = [&](auto s_t) {
+      constexpr int S2 = decltype(s_t)::value;
+      af[S2 % (AD + 1)] = lds_read16<(S2 % TM) * 16 * 128>(a16a[S2 / TM]);
+    };
+    [&]<int... S>(std::integer_sequence<int, S...>) { (read_a16(std::integral_constant<int, S>{}), ...); }(std::make_integer_sequence<int, AD>{});
+    // e4m3 operand of row tile i (two 16-byte reads): row tile i + 1 is read into the other buffer before the MFMAs of row tile i
+    bf16x8 ax[2], ay[2];
+    auto read_8 = [&](auto i_t) {
+      constexpr int I = decltype(i_t)::value, O = I * 16 * 64;
+      if constexpr (I & 1) { ay[0] = lds_read16<O>(a8a[0]); ay[1] = lds_read16<O>(a8a[1]); }
+      else { ax[0] = lds_read16<O>(a8a[0]); ax[1] = lds_read16<O>(a8a[1]); }
+    };
+    constexpr bool EARLY8 = !MULTI;
+    [&]<int... S>(std::integer_sequence<int, S...>) {
+      ([&] {
+        constexpr int ks = S / TM, i = S % TM;
+        if constexpr (S + AD < KS * TM) read_a16(std::integral_constant<int, S + AD>{});
+        if constexpr (EARLY8 && S == KS * TM - 1) read_8(std::integral_constant<int, 0>{});
+        if constexpr (PF && ks == 0) {
+          [&]<int... O>(std::integer_sequence<int, O...>) {
+            ([&] { constexpr int op = i * DMA_PER_STEP + O; if constexpr (op < NDMA) dma(std::integral_constant<int, op>{}, nxt); }(), ...);
+          }(std::make_integer_sequence<int, DMA_PER_STEP>{});
+        }
+        constexpr int AHEAD = (KS * TM - 1 - S < AD ? KS * TM - 1 - S : AD) + (EARLY8 && S >= KS * TM - 1 ? 2 : 0);
+        lgkm_wait<AHEAD>(af[S % (AD + 1)]);
+#if AWT_GEMM_WDEC
+        if constexpr (i == 0) wait_vm<ORD::template w16_wait<PF>(ks)>(w16[ks][0], w16[ks][1], w16[ks][2], w16[ks][3]);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = mfma16<true>(af[S % (AD + 1)], w16[ks][j], acc[i][j]);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (PF && i == TM - 1) load_w16(std::integral_constant<int, ks>{});
+      }(), ...);
+    }(std::make_integer_sequence<int, KS * TM>{});
+    // ---- e4m3 part
+    wait_vm<ORD::template w8_wait<PF>()>();
+    if constexpr (!EARLY8) read_8(std::integral_constant<int, 0>{});
+    [&]<int... I>(std::integer_sequence<int, I...>) {
+      ([&] {
+        if constexpr (I + 1 < TM) read_8(std::integral_constant<int, I + 1>{});
+        bf16x8 (&cur)[2] = (I & 1) ? ay : ax;
+        lgkm_wait<(I + 1 < TM ? 2 : 0)>(cur[0], cur[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        const i32x8 a8 = cat8(cur[0], cur[1]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[I][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, cat8(w8[j][0], w8[j][1]), acc[I][j], 0, 0, 0, e8m0(-kF8Act), 0, e8m0(-kF8Wgt - kF8Lo));
+        __builtin_amdgcn_sched_barrier(0);
+      }(), ...);
+    }(std::make_integer_sequence<int, TM>{});
+    if constexpr (PF) {
+      load_w8();
+#if AWT_GEMM_WDEC
+      wait_vm<ORD::dma_wait_at_barrier()>();
+#else
+      wait_vm<ORD::w16_wait_at_barrier()>();
+#endif
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if constexpr (PF) {
+      const int flip = (kt & 1) ? -STAGE : STAGE;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) a16a[ks] += flip;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) a8a[q] += flip;
+    }
+  };
+  for (int kt = 0; kt + 1 < ktiles; ++kt) ktile(std::true_type{}, kt);
+  ktile(std::false_type{}, ktiles - 1);
+
+  // ---- epilogue: as gemm_f8_kernel (32-row x 64-column strips through a per-wave LDS patch, eight columns per lane), fed from the 16 x 16 C layout:
+  // strip i = row tiles 2 i, 2 i + 1; tile (rt, ct) register reg sits at patch row rt 16 + 4 kq + reg, column ct 16 + r16
+  constexpr int PITCH = 72;
+  float* patch = reinterpret_cast<float*>(smem) + wave * (32 * PITCH);
+  const int c8 = (lane & 7) * 8, r8 = lane >> 3;
+  const int em0 = m0, en = n0 + wc * 64 + c8;
+  float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+  if (g.out.bias && en < g.out.n_valid) { b0 = *reinterpret_cast<const float4*>(g.out.bias + en); b1 = *reinterpret_cast<const float4*>(g.out.bias + en + 4); }
+  constexpr bool SIDE = EPI == EPI_F32_RESID || EPI == EPI_F32_GELU_POS || EPI == EPI_BF16_DGELU;
+  auto strips = [&](auto full_t) {
+    constexpr bool FULL = decltype(full_t)::value;
+    float4 side[4][2], side_next[4][2];
+    auto load_sides = [&](float4 (&d)[4][2], int i) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        d[it][0] = load_side4<EPI, FULL>(g.out, em0 + i * 32 + r8 + 8 * it, en, g.M);
+        d[it][1] = load_side4<EPI, FULL>(g.out, em0 + i * 32 + r8 + 8 * it, en + 4, g.M);
+      }
+    };
+    if constexpr (SIDE) load_sides(side, 0);
+#pragma unroll
+    for (int i = 0; i < TM / 2; ++i) {
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < TN; ++ct)
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) patch[(rt * 16 + 4 * kq + reg) * PITCH + ct * 16 + r16] = acc[2 * i + rt][ct][reg];
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if constexpr (SIDE) { if (i + 1 < TM / 2) load_sides(side_next, i + 1); }
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int rl = r8 + 8 * it;
+        const float4 v0 = *reinterpret_cast<const float4*>(patch + rl * PITCH + c8), v1 = *reinterpret_cast<const float4*>(patch + rl * PITCH + c8 + 4);
+        store_out8_f8<EPI, FULL>(g.out, em0 + i * 32 + rl, en, v0, v1, side[it][0], side[it][1], b0, b1, g.M);
+      }
+      if constexpr (SIDE) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) { side[it][0] = side_next[it][0]; side[it][1] = side_next[it][1]; }
+      }
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  };
+  if (m0 + BM <= g.M && n0 + BN <= g.out.n_valid) strips(std::true_type{}); else strips(std::false_type{});
+}
+
+int g_mfma16 = 1;   // tuning knob "gemm_mfma16": 1 = the 16 x 16 form wherever its weight copies exist (default), 0 = the 32 x 32 kernels only
+template <int EPI>
+int launch_f8s(GemmArgs a, hipStream_t s) {
+  constexpr int lds = 2 * (128 * 64 * 2 + 2 * 128 * 64);
+  a.tiles_m = (a.M + 127) / 128;
+  a.tiles_n = a.N / 256;
+  a.group_n = 0; a.gm = g_gm;
+  AWT_ONCE_PER_DEVICE(AWT_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_f8s_kernel<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)));
+  hipLaunchKernelGGL((gemm_f8s_kernel<EPI, false>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
+  AWT_HIP_CHECK(hipGetLastError());
+  return AWT_OK;
 }
 
 template <int EPI, class CFG>
@@ -1275,6 +1567,9 @@ int launch_epi(GemmArgs a, int prec, hipStream_t s) {
       int tile = g_force_tile;
       if (!tile) tile = (a.N % 256 == 0 && t256f >= kSlots) ? 256 : 128;
       if (tile == 512 && a.N % 256 == 0 && a.nseg == 1) return launch_f8<EPI, CfgF8Big>(a, s);
+      // the 16 x 16 MFMA form: one segment that carries its 16-row weight copies and takes no fp16-exact shortcut (multi-segment K loops keep the 32 x 32
+      // kernel: their per-segment address state does not fit beside the 16 x 16 form's fragment rings)
+      if (tile == 256 && a.N % 256 == 0 && g_mfma16 && a.nseg == 1 && a.seg[0].ws16 && a.seg[0].ws8 && a.seg[0].a8 && !a.seg[0].w_exact16) return launch_f8s<EPI>(a, s);
       if (tile >= 256 && a.N % 256 == 0) return launch_f8<EPI, CfgF8W4>(a, s);
       return launch_f8<EPI, CfgF8Sq>(a, s);
     }
@@ -1381,6 +1676,7 @@ int launch_gemm_pp(awt_ctx* c, int M, int N, const GemmSeg& seg, GemmEpilogue ep
   return awt_fail(AWT_ERR_INVALID, "gemm (ping-pong): unsupported epilogue");
 }
 
+void awt_gemm_set_mfma16(int v) { g_mfma16 = v; }
 void awt_gemm_force_tile(int t) { g_force_tile = t; }
 void awt_gemm_set_gm(int v) { g_gm = v > 0 ? v : AWT_GEMM_GM; }
 

@@ -36,12 +36,20 @@ constexpr int REGION = 16384, BUF = 65536;
 constexpr int OFF_A0 = 0, OFF_B0 = 16384, OFF_B1 = 32768, OFF_A1 = 49152;     // region order inside a K-tile buffer
 constexpr int PATCH_BASE = BUF + OFF_B1;                                      // 98304: the epilogue's 8 x 8 KB transposition patches
 constexpr int LDS_BYTES = PATCH_BASE + 8 * 8192;                              // 163840 = all of a CU's LDS
-enum { FMT_F16 = 0, FMT_F16_16 = 1 /* bring-up harness only: the single product on v_mfma_f32_16x16x32_f16 */, FMT_F16F8 = 2 };
+// FMT_F16F8S: the f16f8 product on 16 x 16 MFMAs.  The operand rows are SPLIT lines: per 64 consecutive k one 128-byte line of fp16 ("X") followed by one
+// 128-byte line of e4m3 ("Y": activations hi8 x 64 | lo8 x 64, weights lo8 x 64 | hi8 x 64), so the K-tile stream alternates X (even K-tiles, always buffer 0:
+// two v_mfma_f32_16x16x32_f16 per 16 x 16 tile) and Y (odd K-tiles, always buffer 1: one v_mfma_scale_f32_16x16x128_f8f6f4 per tile, lane block kb = lane >> 4
+// multiplying A chunks 2 kb, 2 kb + 1 with the same W chunks -- hi8 x lo8 for kb < 2, lo8 x hi8 above, ONE uniform E8M0 scale per operand because
+// 2^-Act 2^(-Wgt - 11) is the scale of both).  Every phase is 256 matrix-pipe cycles in both kinds of K-tile; everything else (regions, staging order, waits)
+// is the FMT_F16F8 pipeline unchanged.  Under the package power limit the 16 x 16 shapes hold a higher clock (profiles/r04_mfma_shape_mix.txt).
+enum { FMT_F16 = 0, FMT_F16_16 = 1 /* bring-up harness only: the single product on v_mfma_f32_16x16x32_f16 */, FMT_F16F8 = 2, FMT_F16F8S = 3 };
 template <int FMT> struct Acc { f32x16 t[4][2]; };                 // 32 x 32 tiles: rows wr * 128 + i * 32, columns wc * 64 + j * 32
-template <> struct Acc<FMT_F16_16> { f32x4 t[8][4]; };          // 16 x 16 tiles
+template <> struct Acc<FMT_F16_16> { f32x4 t[8][4]; };          // 16 x 16 tiles: rows wr * 128 + i * 16, columns wc * 64 + j * 16
+template <> struct Acc<FMT_F16F8S> { f32x4 t[8][4]; };
 
-__host__ __device__ constexpr int ktile_elems(int fmt) { return fmt == FMT_F16F8 ? 32 : 64; }
-__host__ __device__ constexpr int elem_bytes(int fmt) { return fmt == FMT_F16F8 ? 4 : 2; }
+__host__ __device__ constexpr bool tiles16(int fmt) { return fmt == FMT_F16_16 || fmt == FMT_F16F8S; }
+__host__ __device__ constexpr int ktile_elems(int fmt) { return (fmt == FMT_F16F8 || fmt == FMT_F16F8S) ? 32 : 64; }   // K per K-tile (FMT_F16F8S: 64 per X + Y pair)
+__host__ __device__ constexpr int elem_bytes(int fmt) { return (fmt == FMT_F16F8 || fmt == FMT_F16F8S) ? 4 : 2; }
 
 // Packed weight image: for column tile bn (256 columns), K-tile kt and half s, one 16 KB region in exactly the LDS image order
 // (row rho = (n % 256 / 64) * 32 + n % 32 of half s = n % 64 / 32; chunk c at position c ^ ((rho >> 1) & 7)); FMT_F16F8 chunks:
@@ -100,6 +108,12 @@ __device__ __forceinline__ void lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::
 __device__ __forceinline__ i32x8 cat8(bf16x8 lo, bf16x8 hi) {
   typedef int i32x4_t __attribute__((ext_vector_type(4)));
   return __builtin_shufflevector(__builtin_bit_cast(i32x4_t, lo), __builtin_bit_cast(i32x4_t, hi), 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// one Y-line product (FMT_F16F8S): a template on the accumulator type so that the 32 x 32 formats' instantiations of the K loop never see the call
+template <class ACC>
+__device__ __forceinline__ void mfma_y(ACC& c, bf16x8 a0, bf16x8 a1, bf16x8 b0, bf16x8 b1) {
+  if constexpr (sizeof(ACC) == 16) c = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(cat8(a0, a1), cat8(b0, b1), c, 0, 0, 0, e8m0(-kF8Act), 0, e8m0(-kF8Wgt - kF8Lo));
 }
 
 // The K loop of one persistent workgroup.  EPI is a callable  epi(tm, tn, acc)  invoked by all eight waves at the end of every output
@@ -177,6 +191,10 @@ __device__ __forceinline__ void kloop(const Args& g, char* smem, EPI&& epi) {
       const int r16 = lane & 15, f16 = (r16 >> 1) & 7, chunk = 4 * (x & 1) + (lane >> 4);
       aaddr[x] = lds0 + (wr * 64 + r16) * 128 + ((chunk ^ f16) << 4);
       baddr[x] = lds0 + (wc * 32 + r16) * 128 + ((chunk ^ f16) << 4);
+    } else if constexpr (FMT == FMT_F16F8S) {   // x = 0, 1: X line (buffer 0), fp16 k-step x: chunk 4 x + kq;  x = 2, 3: Y line (buffer 1), half q = x - 2 of block kq: chunk 2 kq + q
+      const int r16 = lane & 15, f16 = (r16 >> 1) & 7, kq = lane >> 4, chunk = x < 2 ? 4 * x + kq : 2 * kq + (x - 2);
+      aaddr[x] = lds0 + (x < 2 ? 0 : BUF) + (wr * 64 + r16) * 128 + ((chunk ^ f16) << 4);
+      baddr[x] = lds0 + (x < 2 ? 0 : BUF) + (wc * 32 + r16) * 128 + ((chunk ^ f16) << 4);
     } else {
       const int chunk = (FMT == FMT_F16F8 && x >= 2) ? 4 + 2 * half + (x - 2) : 2 * x + half;
       aaddr[x] = lds0 + (wr * 64 + r32) * 128 + ((chunk ^ f) << 4);
@@ -184,23 +202,27 @@ __device__ __forceinline__ void kloop(const Args& g, char* smem, EPI&& epi) {
     }
   }
   auto flip = [&]() {
+    if constexpr (FMT != FMT_F16F8S) {      // FMT_F16F8S: the X addresses always point into buffer 0, the Y addresses into buffer 1
 #pragma unroll
-    for (int x = 0; x < 4; ++x) { aaddr[x] ^= BUF; baddr[x] ^= BUF; }
+      for (int x = 0; x < 4; ++x) { aaddr[x] ^= BUF; baddr[x] ^= BUF; }
+    }
   };
-  auto read_a = [&](auto s_t, FragA<FMT>& a) {
-    constexpr int base = decltype(s_t)::value ? OFF_A1 : OFF_A0;
+  // par_t: parity of the K-tile being read (FMT_F16F8S only: 0 = X line, 1 = Y line)
+  auto read_a = [&](auto s_t, FragA<FMT>& a, auto par_t) {
+    constexpr int base = decltype(s_t)::value ? OFF_A1 : OFF_A0, par = decltype(par_t)::value;
     static_for<4>([&](auto x_t) {
       constexpr int x = decltype(x_t)::value;
-      if constexpr (FMT == FMT_F16_16) {   // a.v[i][x]: row tile 2 i + (x >> 1) of 16 rows, k-step x & 1
-        a.v[0][x] = dsr<base + (x >> 1) * 2048>(aaddr[x & 1]); a.v[1][x] = dsr<base + 4096 + (x >> 1) * 2048>(aaddr[x & 1]);
+      if constexpr (tiles16(FMT)) {   // a.v[i][x]: row tile 2 i + (x >> 1) of 16 rows, k-step (X) / half (Y) x & 1
+        constexpr int ai = (FMT == FMT_F16F8S ? 2 * par : 0) + (x & 1);
+        a.v[0][x] = dsr<base + (x >> 1) * 2048>(aaddr[ai]); a.v[1][x] = dsr<base + 4096 + (x >> 1) * 2048>(aaddr[ai]);
       } else { a.v[0][x] = dsr<base>(aaddr[x]); a.v[1][x] = dsr<base + 4096>(aaddr[x]); }
     });
   };
-  auto read_b = [&](auto s_t, FragB<FMT>& b) {
-    constexpr int base = decltype(s_t)::value ? OFF_B1 : OFF_B0;
+  auto read_b = [&](auto s_t, FragB<FMT>& b, auto par_t) {
+    constexpr int base = decltype(s_t)::value ? OFF_B1 : OFF_B0, par = decltype(par_t)::value;
     static_for<4>([&](auto x_t) {
       constexpr int x = decltype(x_t)::value;
-      if constexpr (FMT == FMT_F16_16) b.v[x] = dsr<base + (x >> 1) * 2048>(baddr[x & 1]);   // column tile x >> 1 of 16, k-step x & 1
+      if constexpr (tiles16(FMT)) b.v[x] = dsr<base + (x >> 1) * 2048>(baddr[(FMT == FMT_F16F8S ? 2 * par : 0) + (x & 1)]);   // column tile x >> 1 of 16, k-step / half x & 1
       else b.v[x] = dsr<base>(baddr[x]);
     });
   };
@@ -213,7 +235,7 @@ __device__ __forceinline__ void kloop(const Args& g, char* smem, EPI&& epi) {
   Acc<FMT> accs;
   auto& acc = accs.t;
   auto zero_acc = [&]() {
-    if constexpr (FMT == FMT_F16_16) {
+    if constexpr (tiles16(FMT)) {
 #pragma unroll
       for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -225,11 +247,19 @@ __device__ __forceinline__ void kloop(const Args& g, char* smem, EPI&& epi) {
         for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16){};
     }
   };
-  auto mma = [&](auto sa_t, auto sb_t, const FragA<FMT>& a, const FragB<FMT>& b) {
-    constexpr int sa = decltype(sa_t)::value, sb = decltype(sb_t)::value;
+  auto mma = [&](auto sa_t, auto sb_t, const FragA<FMT>& a, const FragB<FMT>& b, auto par_t) {
+    constexpr int sa = decltype(sa_t)::value, sb = decltype(sb_t)::value, par = decltype(par_t)::value;
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
-    if constexpr (FMT == FMT_F16_16) {
+    if constexpr (FMT == FMT_F16F8S && par == 1) {     // Y line: both cross terms of 64 k in one block-scaled MFMA per 16 x 16 tile
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+          mfma_y(acc[4 * sa + rt][2 * sb + ct], a.v[rt >> 1][(rt & 1) * 2], a.v[rt >> 1][(rt & 1) * 2 + 1], b.v[ct * 2], b.v[ct * 2 + 1]);
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) asm volatile("" : "+v"(acc[4 * sa + rt][2 * sb]), "+v"(acc[4 * sa + rt][2 * sb + 1]));
+    } else if constexpr (tiles16(FMT)) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -279,37 +309,37 @@ __device__ __forceinline__ void kloop(const Args& g, char* smem, EPI&& epi) {
   auto pair = [&](auto last_t) {
     constexpr bool LAST = decltype(last_t)::value;
     // ================= even K-tile (buffer 0): B0 is in rba
-    read_a(I0{}, ra); stage_a(I1{}, I1{}); vmwait<10>(); bar();
-    lgkm0(); tie(ra); tie(rba); mma(I0{}, I0{}, ra, rba); bar();
+    read_a(I0{}, ra, I0{}); stage_a(I1{}, I1{}); vmwait<10>(); bar();
+    lgkm0(); tie(ra); tie(rba); mma(I0{}, I0{}, ra, rba, I0{}); bar();
     if constexpr (LAST) wb[0] = w_base(tn1, 0);
-    read_b(I1{}, rbb); stage_b(I0{}, I0{}); vmwait<10>(); bar();
-    lgkm0(); tie(rbb); mma(I0{}, I1{}, ra, rbb); bar();
+    read_b(I1{}, rbb, I0{}); stage_b(I0{}, I0{}); vmwait<10>(); bar();
+    lgkm0(); tie(rbb); mma(I0{}, I1{}, ra, rbb, I0{}); bar();
     if constexpr (LAST) ab[0] = a_base(tm1, 0);
-    read_a(I1{}, ra); stage_a(I0{}, I0{}); vmwait<10>(); bar();
-    lgkm0(); tie(ra); mma(I1{}, I1{}, ra, rbb); bar();
+    read_a(I1{}, ra, I0{}); stage_a(I0{}, I0{}); vmwait<10>(); bar();
+    lgkm0(); tie(ra); mma(I1{}, I1{}, ra, rbb, I0{}); bar();
     if constexpr (LAST) wb[1] = w_base(tn1, 1);
     flip();
-    read_b(I0{}, rbb); stage_b(I1{}, I0{}); vmwait<8>(); bar();          // next K-tile's B0 (buffer 1) into the set M3 just released
-    mma(I1{}, I0{}, ra, rba); bar();
+    read_b(I0{}, rbb, I1{}); stage_b(I1{}, I0{}); vmwait<8>(); bar();          // next K-tile's B0 (buffer 1) into the set M3 just released
+    mma(I1{}, I0{}, ra, rba, I0{}); bar();
     // ================= odd K-tile (buffer 1): B0 is in rbb
     if constexpr (LAST) ab[1] = a_base(tm1, 1);
-    read_a(I0{}, ra); stage_a(I1{}, I0{}); vmwait<10>(); bar();
-    lgkm0(); tie(ra); tie(rbb); mma(I0{}, I0{}, ra, rbb); bar();
-    read_b(I1{}, rba); stage_b(I0{}, I1{}); vmwait<10>(); bar();
-    lgkm0(); tie(rba); mma(I0{}, I1{}, ra, rba); bar();
-    read_a(I1{}, ra); stage_a(I0{}, I1{}); vmwait<10>(); bar();
-    lgkm0(); tie(ra); mma(I1{}, I1{}, ra, rba); bar();
+    read_a(I0{}, ra, I1{}); stage_a(I1{}, I0{}); vmwait<10>(); bar();
+    lgkm0(); tie(ra); tie(rbb); mma(I0{}, I0{}, ra, rbb, I1{}); bar();
+    read_b(I1{}, rba, I1{}); stage_b(I0{}, I1{}); vmwait<10>(); bar();
+    lgkm0(); tie(rba); mma(I0{}, I1{}, ra, rba, I1{}); bar();
+    read_a(I1{}, ra, I1{}); stage_a(I0{}, I1{}); vmwait<10>(); bar();
+    lgkm0(); tie(ra); mma(I1{}, I1{}, ra, rba, I1{}); bar();
     flip();
-    if constexpr (!LAST) { read_b(I0{}, rba); stage_b(I1{}, I1{}); }
+    if constexpr (!LAST) { read_b(I0{}, rba, I0{}); stage_b(I1{}, I1{}); }
     vmwait<8>(); bar();
-    mma(I1{}, I0{}, ra, rbb); bar();
+    mma(I1{}, I0{}, ra, rbb, I1{}); bar();
   };
 
   for (int it = 0; it < nmine; ++it) {
     zero_acc();
     if (wr == 1) bar();                                  // waves 4-7 run one barrier interval behind from here on
     // pre-phase: first B0 of the tile, and the region staging that the previous tile's last phase deferred (B1 of K-tile 1)
-    read_b(I0{}, rba);
+    read_b(I0{}, rba, I0{});
     stage_b(I1{}, I1{});
     for (int kp = 2; kp < nk; kp += 2) pair(std::false_type{});
     pair(std::true_type{});

@@ -54,6 +54,46 @@ def test_linear_ping_pong(M, N, K):
     assert torch.equal(y, y2)                       # deterministic (no atomics, fixed tile -> workgroup map)
 
 
+# The 16 x 16 MFMA form of the f16f8 GEMM (gemm_f8s_kernel; tuning knob "gemm_mfma16", default on): the same arithmetic as the 32 x 32 kernel from different
+# fragment layouts (16-row weight copies, one scaled MFMA for both cross terms) -- checked against fp64 and against the 32 x 32 kernel on shapes that select the
+# 256-wide tile: ragged M, every encoder K (384 / 768 / 1280 / 3072 / 5120), and an asymmetric identity-like case that would expose a transposed or permuted layout
+@pytest.mark.parametrize("M,N,K", [(3000, 768, 768), (2999, 2304, 768), (4100, 768, 3072), (6000, 1536, 384), (3000, 1280, 5120), (36000, 3072, 768)])
+def test_linear_f16f8_on_16x16_mfma(M, N, K):
+    from mlx8_ws_audio_transformer_amd import _lib, ops
+    x, w, b = _rand((M, K), 1), _rand((N, K), 2, K ** -0.5), _rand((N,), 3)
+    ref = torch.nn.functional.linear(x.double(), w.double(), b.double())
+    _lib.tuning_set("gemm_tile", 256)
+    try:
+        y = ops.linear(x, w, b, "f16f8")
+        y2 = ops.linear(x, w, b, "f16f8")
+        _lib.tuning_set("gemm_mfma16", 0)
+        y32 = ops.linear(x, w, b, "f16f8")
+    finally:
+        _lib.tuning_set("gemm_mfma16", 1)
+        _lib.tuning_set("gemm_tile", 0)
+    err, err32 = (y.double() - ref).abs().max().item(), (y32.double() - ref).abs().max().item()
+    print((M, N, K), "16x16 max-abs", err, "32x32", err32, "between", (y - y32).abs().max().item())
+    assert err < TOL["f16f8"] * max(1.0, ref.abs().max().item()), err
+    assert torch.equal(y, y2)
+    assert (y - y32).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())    # the same products, another fp32 summation order
+
+
+def test_linear_f16f8_on_16x16_mfma_places_every_element():
+    # x = rows of a permutation-like matrix, W with a distinct value per (n, k): a swapped fragment lane, K block or C register shows up as a wrong element
+    from mlx8_ws_audio_transformer_amd import _lib, ops
+    M, N, K = 4096, 512, 256
+    x = torch.zeros(M, K)
+    x[torch.arange(M), (torch.arange(M) * 7) % K] = 1.0
+    w = ((torch.arange(N * K, dtype=torch.float32).reshape(N, K) * 37) % 1021 - 510) / 1024 + 1e-4     # not fp16-exact: keeps the general kernel
+    _lib.tuning_set("gemm_tile", 256)
+    try:
+        y = ops.linear(x.cuda(), w.cuda(), None, "f16f8").cpu()
+    finally:
+        _lib.tuning_set("gemm_tile", 0)
+    ref = w.t()[(torch.arange(M) * 7) % K]
+    assert (y - ref).abs().max().item() < 1e-6
+
+
 def test_tuning_set_rejects_unknown():
     from mlx8_ws_audio_transformer_amd import _lib
     with pytest.raises(_lib.AwtError):

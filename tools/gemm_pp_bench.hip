@@ -49,6 +49,19 @@ __global__ void pack_a_ilv(char* A, int M, int K, unsigned seed) {   // interlea
   *reinterpret_cast<unsigned*>(line + 64 + g * 4) = hi8;
   *reinterpret_cast<unsigned*>(line + 96 + g * 4) = lo8;
 }
+__global__ void pack_a_split(char* A, int M, int K, unsigned seed) {   // split lines [M][K / 64][fp16 x 64 | hi8 x 64 | lo8 x 64] (FMT_F16F8S)
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)M * K / 4) return;
+  const long long e = i * 4; const int m = (int)(e / K), k = (int)(e % K), grp = k >> 6, kk = k & 63;
+  float v[4];
+  for (int t = 0; t < 4; ++t) v[t] = gen(seed, e + t);
+  uint2 h16; unsigned hi8, lo8;
+  f16f8x4<kF8Act>(v, h16, hi8, lo8);
+  char* line = A + ((long long)m * (K / 64) + grp) * 256;
+  *reinterpret_cast<uint2*>(line + kk * 2) = h16;
+  *reinterpret_cast<unsigned*>(line + 128 + kk) = hi8;
+  *reinterpret_cast<unsigned*>(line + 192 + kk) = lo8;
+}
 template <int FMT>
 __global__ void pack_w(char* W, int N, int Npad, int K, unsigned seed, float scale) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -60,7 +73,16 @@ __global__ void pack_w(char* W, int N, int Npad, int K, unsigned seed, float sca
   for (int t = 0; t < 4; ++t) v[t] = n < N ? gen(seed, (long long)n * K + k + t) * scale : 0.0f;
   const int bn = n >> 8, nin = n & 255, s = (nin >> 5) & 1;
   char* reg = W + pp::w_region_offset(bn, kt, s, nk);
-  if (FMT != pp::FMT_F16F8) {
+  if (FMT == pp::FMT_F16F8S) {   // 64-deep groups: fp16 into the X K-tile 2 grp (chunk = kk / 8), lo8 | hi8 into the Y K-tile 2 grp + 1 (chunks kk / 16, 4 + kk / 16)
+    const int grp = k >> 6, k6 = k & 63;
+    uint2 h16; unsigned hi8, lo8;
+    f16f8x4<kF8Wgt>(v, h16, hi8, lo8);
+    char* rx = W + pp::w_region_offset(bn, 2 * grp, s, nk);
+    char* ry = W + pp::w_region_offset(bn, 2 * grp + 1, s, nk);
+    *reinterpret_cast<uint2*>(rx + pp::w_row_offset(nin, k6 >> 3) + (k6 & 7) * 2) = h16;
+    *reinterpret_cast<unsigned*>(ry + pp::w_row_offset(nin, k6 >> 4) + (k6 & 15)) = lo8;
+    *reinterpret_cast<unsigned*>(ry + pp::w_row_offset(nin, 4 + (k6 >> 4)) + (k6 & 15)) = hi8;
+  } else if (FMT != pp::FMT_F16F8) {
     const int g = kk >> 2;
     *reinterpret_cast<uint2*>(reg + pp::w_row_offset(nin, g >> 1) + (g & 1) * 8) = make_uint2(pack2(f32_to_f16(v[0]), f32_to_f16(v[1])), pack2(f32_to_f16(v[2]), f32_to_f16(v[3])));
   } else {
@@ -83,9 +105,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_test(pp::Args g, TestOut o) {
   if constexpr (EPI == 2) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
   pp::kloop<FMT>(g, smem, [&](int tm, int tn, pp::Acc<FMT>& accs) {
     auto& acc = accs.t;
-    if constexpr (EPI == 0 || EPI == 2 || FMT == pp::FMT_F16_16) {
+    if constexpr (EPI == 0 || EPI == 2 || pp::tiles16(FMT)) {
       float s = 0.f;
-      constexpr int NI = FMT == pp::FMT_F16_16 ? 8 : 4, NJ = FMT == pp::FMT_F16_16 ? 4 : 2, NR = FMT == pp::FMT_F16_16 ? 4 : 16;
+      constexpr int NI = pp::tiles16(FMT) ? 8 : 4, NJ = pp::tiles16(FMT) ? 4 : 2, NR = pp::tiles16(FMT) ? 4 : 16;
 #pragma unroll
       for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -158,7 +180,8 @@ static void prepare(const Problem& p, char*& A, char*& W, unsigned seed) {
   CK(hipMalloc(&A, ab)); CK(hipMalloc(&W, wbytes));
   CK(hipMemset(A, 0, ab));
   const long long na = (long long)p.M * p.K / 4, nw = (long long)Npad * p.K / 4;
-  if (FMT != pp::FMT_F16F8) hipLaunchKernelGGL(pack_a_f16, dim3((na + 255) / 256), dim3(256), 0, 0, A, p.M, p.K, seed);
+  if (FMT == pp::FMT_F16F8S) hipLaunchKernelGGL(pack_a_split, dim3((na + 255) / 256), dim3(256), 0, 0, A, p.M, p.K, seed);
+  else if (FMT != pp::FMT_F16F8) hipLaunchKernelGGL(pack_a_f16, dim3((na + 255) / 256), dim3(256), 0, 0, A, p.M, p.K, seed);
   else hipLaunchKernelGGL(pack_a_ilv, dim3((na + 255) / 256), dim3(256), 0, 0, A, p.M, p.K, seed);
   hipLaunchKernelGGL((pack_w<FMT>), dim3((nw + 255) / 256), dim3(256), 0, 0, W, p.N, Npad, p.K, seed + 1, 1.0f / sqrtf((float)p.K));
   CK(hipDeviceSynchronize());
@@ -181,7 +204,7 @@ static bool check(const Problem& p, int grid_limit) {
       double ref = 0;
       for (int k = 0; k < p.K; ++k) ref += (double)gen(1234, (long long)m * p.K + k) * (double)(gen(1235, (long long)n * p.K + k) * ws);
       const double err = fabs((double)h[(size_t)m * p.N + n] - ref);
-      if (!(err <= (FMT != pp::FMT_F16F8 ? 2e-2 : 3e-4))) { if (bad < 8) printf("  bad m=%d n=%d got %.6f ref %.6f\n", m, n, h[(size_t)m * p.N + n], ref); ++bad; }
+      if (!(err <= (pp::elem_bytes(FMT) == 2 ? 2e-2 : 3e-4))) { if (bad < 8) printf("  bad m=%d n=%d got %.6f ref %.6f\n", m, n, h[(size_t)m * p.N + n], ref); ++bad; }
       if (err > worst || err != err) worst = err;
       ++nsamp;
     }
@@ -275,9 +298,12 @@ int main(int argc, char** argv) {
       ok &= check<pp::FMT_F16>(p, 3);
       ok &= check<pp::FMT_F16_16>(p, 256);
       ok &= check<pp::FMT_F16_16>(p, 2);
+      ok &= check<pp::FMT_F16F8S>(p, 256);
+      ok &= check<pp::FMT_F16F8S>(p, 2);
     }
     const Problem big = {"qkv", 24000, 2304, 768};
     ok &= check<pp::FMT_F16F8>(big, 256);
+    ok &= check<pp::FMT_F16F8S>(big, 256);
     ok &= check<pp::FMT_F16>(big, 256);
     printf(ok ? "CHECK OK\n" : "CHECK FAILED\n");
     if (!ok) return 1;
@@ -287,6 +313,7 @@ int main(int argc, char** argv) {
     for (const auto& p : shapes) timing<pp::FMT_F16>(p, 10);
     for (const auto& p : shapes) timing<pp::FMT_F16_16>(p, 10);
     for (const auto& p : shapes) timing<pp::FMT_F16F8>(p, 10);
+    for (const auto& p : shapes) timing<pp::FMT_F16F8S>(p, 10);
     const Problem cube = {"4k", 4096, 4096, 4096}, cube8 = {"8k", 8192, 8192, 8192};
     timing<pp::FMT_F16>(cube, 10); timing<pp::FMT_F16_16>(cube, 10); timing<pp::FMT_F16>(cube8, 5); timing<pp::FMT_F16_16>(cube8, 5);
   }
