@@ -333,11 +333,14 @@ int awt_op_attention_small_backward_dropout(awt_ctx* c, const float* q, int ldq,
  * automatic; 1..5 keep the e4m3 cross terms of P V (plain 4x32 / 4x64 / 6x32 queries, software-pipelined 4 / 8 waves), 6 / 7 =
  * software-pipelined 4 / 8 waves with P V as one fp16 product (what 0 selects for inference).  Only the last choice changes
  * results (within the tolerances of DESIGN.md section 3); every other value is bit-neutral.
- * "gemm_pp": the persistent 256 x 256 eight-wave "ping-pong" f16f8 GEMM (csrc/gemm_pp.h: both operands by LDS-DMA, interleaved-line
- * activations, one workgroup per CU walking its tiles): 0 = off (default: on the encoder's shapes it ties the 128 x 256 kernels end to
- * end), 1 = automatic (inference launches of >= 256 tiles on weights that are not fp16-exact), 2 = wherever it applies (N % 256 == 0,
- * K % 64 == 0, K >= 128, no adapter; also awt_op_linear).  Same accumulation order per output, so results differ from the default
- * tiling only by the e4m3 cross terms' grouping (<= 1e-4 on hidden states). */
+ * "gemm_pp": the persistent 256 x 256 eight-wave "ping-pong" f16f8 GEMM (csrc/gemm_pp.h: both operands by LDS-DMA, split-line
+ * activations, 16 x 16 MFMAs, one workgroup per CU walking its tiles): 0 = off, 1 = automatic (default: inference launches of >= 256
+ * tiles on weights that are not fp16-exact), 2 = wherever it applies (N % 256 == 0, K % 64 == 0, K >= 128, no adapter; also
+ * awt_op_linear).  "gemm_pp_mask": which projections of a layer may take it, a bit set (1 qkv, 2 out_proj, 4 fc1, 8 fc2; fc2 only with
+ * fc1; default 12 = the MLP pair, where it is measurably ahead).  Same products and the same accumulation order per output as the
+ * 128 x 256 kernel's 16 x 16 form: bit-identical results where both apply.
+ * "gemm_mfma16": 1 (default) = the 128 x 256 f16f8 GEMM issues its products as 16 x 16 MFMAs (both e4m3 cross terms in one block-scaled
+ * instruction), 0 = the 32 x 32 form (results differ by the fp32 summation order only). */
 int awt_tuning_set(const char* key, int value);
 
 /* ------------------------------------------------------------------------------------------------------

@@ -707,7 +707,7 @@ int launch_attention_f16f8(awt_ctx* c, const F8Planes& q, const F8Planes& k, con
   AWT_REQUIRE(q.p16 && q.hi8 && q.lo8 && k.p16 && k.hi8 && k.lo8 && v.p16 && v.hi8 && v.lo8, AWT_ERR_INVALID, "attention (f16f8): null plane");
   // (v.hi8 / v.lo8 are only dereferenced by the forms attention_f16f8_reads_v8() names; the encoder does not fill them otherwise)
   AWT_REQUIRE(o_f32 || o_ilv || (o.p16 && o.lo8), AWT_ERR_INVALID, "attention (f16f8): null output plane (hi8 may be null: not consumed)");
-  AWT_REQUIRE(!o_ilv || (H * 64) % 32 == 0, AWT_ERR_INVALID, "attention (f16f8): interleaved-line output needs whole 32-element lines per row");
+  AWT_REQUIRE(!o_ilv || (H * 64) % 64 == 0, AWT_ERR_INVALID, "attention (f16f8): split-line output needs whole 64-element line pairs per row");
   Attn8Args a{q.p16, k.p16, v.p16, q.hi8, q.lo8, k.hi8, k.lo8, v.hi8, v.lo8, o.p16, o.hi8, o.lo8, o_f32, lse, B, H, S};
   a.o_ilv = o_f32 ? nullptr : o_ilv;
   ProfScope prof(c, AWT_PROF_ATTENTION, s, 4.0 * (double)B * H * (double)S * S * 64);

@@ -38,6 +38,7 @@ void awt_prof_end(awt_ctx* c, int klass, hipStream_t s) {
   p->spans[klass].push_back(p->open[klass]);
 }
 
+static int g_pp_mask = 12;   // tuning knob "gemm_pp_mask": which of a layer's four projections may take the ping-pong GEMM (default: fc1 + fc2, profiles/r04_gemm_pp16_masks.txt)
 extern "C" int awt_tuning_set(const char* key, int value) {
   AWT_REQUIRE(key, AWT_ERR_INVALID, "tuning_set: null key");
   if (!strcmp(key, "gemm_tile")) {
@@ -53,6 +54,11 @@ extern "C" int awt_tuning_set(const char* key, int value) {
   if (!strcmp(key, "gemm_pp")) {
     AWT_REQUIRE(value >= 0 && value <= 2, AWT_ERR_INVALID, "tuning_set: gemm_pp must be 0 (off, default), 1 (automatic) or 2 (wherever supported)");
     awt_gemm_set_pp_mode(value);
+    return AWT_OK;
+  }
+  if (!strcmp(key, "gemm_pp_mask")) {
+    AWT_REQUIRE(value >= 0 && value <= 15, AWT_ERR_INVALID, "tuning_set: gemm_pp_mask is a bit set 0 .. 15 (1 qkv, 2 out_proj, 4 fc1, 8 fc2; fc2 only together with fc1)");
+    g_pp_mask = value;
     return AWT_OK;
   }
   if (!strcmp(key, "gemm_mfma16")) {
@@ -461,8 +467,8 @@ int encoder_layer(awt_encoder* e, Layer& L, const LayerBufs& b, int Bc, bool sav
   const int64_t plane = (int64_t)M * d;
   // which of the four linears run on the persistent ping-pong kernel (inference only): their inputs are then written as interleaved lines by the
   // producer (LayerNorm, the attention epilogue, fc1's GELU epilogue) instead of as three planes -- same bytes, same buffers
-  const bool pp_qkv = !save && use_pp(e, L.qkv, L.lq, M, EPI_QKV), pp_out = !save && use_pp(e, L.out, L.lo_, M, EPI_F32_RESID);
-  const bool pp_fc1 = !save && use_pp(e, L.fc1, L.l1, M, EPI_BF16_GELU), pp_fc2 = pp_fc1 && use_pp(e, L.fc2, L.l2, M, EPI_F32_RESID);
+  const bool pp_qkv = !save && (g_pp_mask & 1) && use_pp(e, L.qkv, L.lq, M, EPI_QKV), pp_out = !save && (g_pp_mask & 2) && use_pp(e, L.out, L.lo_, M, EPI_F32_RESID);
+  const bool pp_fc1 = !save && (g_pp_mask & 4) && use_pp(e, L.fc1, L.l1, M, EPI_BF16_GELU), pp_fc2 = pp_fc1 && (g_pp_mask & 8) && use_pp(e, L.fc2, L.l2, M, EPI_F32_RESID);
   // an activation whose only consumer is a GEMM on fp16-exact weights (gemm.hip, WX) needs no hi8 image: the producers skip that plane
   auto feeds = [&](Act a, const Linear& lin, const LoraGroup& lg) { if (terms == PREC_F16F8 && lin.w.exact16 && !lg.active) a.hi8 = nullptr; return a; };
   const Act aqkv = make_act(b.qkv[0], b.qkv[1], 3 * (size_t)plane, terms);

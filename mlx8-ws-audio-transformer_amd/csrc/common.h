@@ -225,16 +225,16 @@ __host__ __device__ __forceinline__ int64_t w8s_index(int n, int k, int ktiles64
 }
 
 // An activation matrix as MFMA operand planes: p16 (bf16 or fp16) + lo16 (split modes) or + hi8 / lo8 (f16f8).
-// ilv (PREC_F16F8 only, instead of the three planes): the INTERLEAVED-LINE image the ping-pong GEMM (gemm_pp.h) stages by whole cache
-// lines -- a dense [M][K] matrix, K % 32 == 0, as [M][K / 32] lines of 128 bytes = the 32 elements' fp16 | hi8 | lo8 (64 + 32 + 32 bytes),
-// so that element offset `off` (a multiple of 4) lives in line off >> 5 at group g = (off & 31) >> 2: fp16 bytes 8 g, hi8 64 + 4 g, lo8 96 + 4 g.
+// ilv (PREC_F16F8 only, instead of the three planes): the SPLIT-LINE image the ping-pong GEMM (gemm_pp.h, FMT_F16F8S) stages by whole cache
+// lines -- a dense [M][K] matrix, K % 64 == 0, as [M][K / 64] pairs of 128-byte lines: the 64 elements' fp16 (the "X" line), then their hi8 x 64 | lo8 x 64
+// (the "Y" line), so that element offset `off` lives in pair off >> 6 (256 bytes) at e = off & 63: fp16 byte 2 e, hi8 byte 128 + e, lo8 byte 192 + e.
 struct Act { bf16_t* p16 = nullptr; bf16_t* lo16 = nullptr; uint8_t* hi8 = nullptr; uint8_t* lo8 = nullptr; char* ilv = nullptr; };
 __device__ __forceinline__ void store_ilv4(char* ilv, int64_t off, uint2 h16, unsigned hi8, unsigned lo8) {
-  char* line = ilv + (off >> 5) * 128;
-  const int g = (int)(off & 31) >> 2;
-  *reinterpret_cast<uint2*>(line + g * 8) = h16;
-  *reinterpret_cast<unsigned*>(line + 64 + g * 4) = hi8;
-  *reinterpret_cast<unsigned*>(line + 96 + g * 4) = lo8;
+  char* line = ilv + (off >> 6) * 256;
+  const int e = (int)(off & 63);
+  *reinterpret_cast<uint2*>(line + e * 2) = h16;
+  *reinterpret_cast<unsigned*>(line + 128 + e) = hi8;
+  *reinterpret_cast<unsigned*>(line + 192 + e) = lo8;
 }
 // four consecutive elements at element offset `off` (a multiple of 4) in the planes of precision PREC; S = e4m3 exponent
 template <int PREC, int S = kF8Act, bool SAT = false>

@@ -141,8 +141,9 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
   if ((PREC == PREC_F16F8 || PREC == PREC_F16X3) && inexact && __builtin_amdgcn_ballot_w64(any_inexact) != 0 && (threadIdx.x & 63) == 0) atomicOr(inexact, 1);
 }
 
-// The packed weight image of the ping-pong GEMM (gemm_pp.h): per (256-column tile, 32-deep K-tile, half) one 16 KB region in LDS image order, each
-// row a 128-byte line fp16 x 32 | lo8 x 32 | hi8 x 32 with its 16-byte chunks XOR-swizzled by the row.  One thread per four consecutive k of a row.
+// The packed weight image of the ping-pong GEMM (gemm_pp.h, FMT_F16F8S): per (256-column tile, K-tile, half) one 16 KB region in LDS image order; the K-tiles
+// alternate between the X line (fp16 x 64) and the Y line (lo8 x 64 | hi8 x 64) of 64 consecutive k, each row's 16-byte chunks XOR-swizzled by the row.
+// One thread per four consecutive k of a row.
 __global__ __launch_bounds__(256) void pack_weight_pp_kernel(const float* __restrict__ src, int N, int K, int row_off, char* dst) {
   const int nk = K >> 5;
   const int64_t total = (int64_t)N * (K >> 2);
@@ -152,11 +153,12 @@ __global__ __launch_bounds__(256) void pack_weight_pp_kernel(const float* __rest
     const float v[4] = {q.x, q.y, q.z, q.w};
     uint2 h16; unsigned hi8, lo8;
     f16f8x4<kF8Wgt>(v, h16, hi8, lo8);
-    const int row = row_off + n, bn = row >> 8, nin = row & 255, sgrp = (nin >> 5) & 1, kt = k >> 5, g = (k & 31) >> 2;
-    char* reg = dst + pp::w_region_offset(bn, kt, sgrp, nk);
-    *reinterpret_cast<uint2*>(reg + pp::w_row_offset(nin, g >> 1) + (g & 1) * 8) = h16;
-    *reinterpret_cast<unsigned*>(reg + pp::w_row_offset(nin, 4 + (g >> 2)) + (g & 3) * 4) = lo8;
-    *reinterpret_cast<unsigned*>(reg + pp::w_row_offset(nin, 6 + (g >> 2)) + (g & 3) * 4) = hi8;
+    const int row = row_off + n, bn = row >> 8, nin = row & 255, sgrp = (nin >> 5) & 1, grp = k >> 6, e = k & 63;
+    char* rx = dst + pp::w_region_offset(bn, 2 * grp, sgrp, nk);
+    char* ry = dst + pp::w_region_offset(bn, 2 * grp + 1, sgrp, nk);
+    *reinterpret_cast<uint2*>(rx + pp::w_row_offset(nin, e >> 3) + (e & 7) * 2) = h16;
+    *reinterpret_cast<unsigned*>(ry + pp::w_row_offset(nin, e >> 4) + (e & 15)) = lo8;
+    *reinterpret_cast<unsigned*>(ry + pp::w_row_offset(nin, 4 + (e >> 4)) + (e & 15)) = hi8;
   }
 }
 
@@ -456,7 +458,7 @@ int launch_layernorm(awt_ctx* c, const float* x, const float* gamma, const float
                      float* out_f32, const Act& out, int prec, hipStream_t s) {
   AWT_REQUIRE(x && gamma && beta && (out_f32 || out.p16 || out.ilv), AWT_ERR_INVALID, "layernorm: null argument");
   AWT_REQUIRE(out_f32 || prec != PREC_F16F8 || out.lo8 || out.ilv, AWT_ERR_INVALID, "layernorm: f16f8 output needs its lo8 plane (hi8 may be null: not consumed)");
-  AWT_REQUIRE(!out.ilv || out_f32 || (prec == PREC_F16F8 && d % 32 == 0), AWT_ERR_INVALID, "layernorm: interleaved lines are an f16f8 format of whole 32-element lines");
+  AWT_REQUIRE(!out.ilv || out_f32 || (prec == PREC_F16F8 && d % 64 == 0), AWT_ERR_INVALID, "layernorm: split lines are an f16f8 format of whole 64-element line pairs");
   AWT_REQUIRE(M > 0 && d > 0 && d % 4 == 0 && d <= 64 * 4 * kLnMaxChunks, AWT_ERR_INVALID, "layernorm: d must be a multiple of 4 and <= 1280");
   ProfScope prof(c, AWT_PROF_LAYERNORM, s, 0.0);
   const dim3 grid((M + 3) / 4), block(256);
@@ -482,7 +484,7 @@ int launch_split_planes(awt_ctx* c, const float* x, int64_t n, float scale, int 
   AWT_REQUIRE(x && (p16 || ilv) && n > 0 && n % 4 == 0, AWT_ERR_INVALID, "split: n must be a positive multiple of 4");
   AWT_REQUIRE(prec == PREC_BF16 || prec == PREC_F16 || prec == PREC_BF16X3 || prec == PREC_F16X3 || prec == PREC_F16F8, AWT_ERR_INVALID, "split: unknown precision");
   AWT_REQUIRE(prec != PREC_F16F8 || (hi8 && lo8) || ilv, AWT_ERR_INVALID, "split: f16f8 needs both e4m3 planes");
-  AWT_REQUIRE(!ilv || (prec == PREC_F16F8 && n % 32 == 0), AWT_ERR_INVALID, "split: interleaved lines are an f16f8 format of whole 32-element lines");
+  AWT_REQUIRE(!ilv || (prec == PREC_F16F8 && n % 64 == 0), AWT_ERR_INVALID, "split: split lines are an f16f8 format of whole 64-element line pairs");
   AWT_REQUIRE(f8_exp >= -20 && f8_exp <= 20, AWT_ERR_INVALID, "split: bad e4m3 exponent");
   ProfScope prof(c, AWT_PROF_OTHER, s, 0.0);
   const int64_t n4 = n / 4;

@@ -298,12 +298,12 @@ __device__ __forceinline__ void store_out8_f8(const GemmOut& o, int m, int n, fl
   bf16_t h[8]; float l[8];
 #pragma unroll
   for (int t = 0; t < 8; ++t) { h[t] = f32_to_f16(v[t]); l[t] = v[t] - f16_to_f32(h[t]); }
-  if constexpr (ILV) {   // interleaved lines (Act::ilv): the eight columns are a quarter q of one 128-byte line: fp16 bytes 16 q, hi8 64 + 8 q, lo8 96 + 8 q
-    char* line = o.ilv + (off >> 5) * 128;
-    const int q = (int)(off & 31) >> 3;
-    __builtin_nontemporal_store((i32x4_t){(int)pack2(h[0], h[1]), (int)pack2(h[2], h[3]), (int)pack2(h[4], h[5]), (int)pack2(h[6], h[7])}, reinterpret_cast<i32x4_t*>(line + q * 16));
-    __builtin_nontemporal_store((i32x2){(int)fp8x4_rt(v[0], v[1], v[2], v[3], lim8, inv8), (int)fp8x4_rt(v[4], v[5], v[6], v[7], lim8, inv8)}, reinterpret_cast<i32x2*>(line + 64 + q * 8));
-    __builtin_nontemporal_store((i32x2){(int)fp8x4_rt(l[0], l[1], l[2], l[3], liml8, invl8), (int)fp8x4_rt(l[4], l[5], l[6], l[7], liml8, invl8)}, reinterpret_cast<i32x2*>(line + 96 + q * 8));
+  if constexpr (ILV) {   // split lines (Act::ilv): the eight columns are an eighth of one 64-element line pair: fp16 bytes 2 e, hi8 128 + e, lo8 192 + e
+    char* line = o.ilv + (off >> 6) * 256;
+    const int e = (int)(off & 63);
+    __builtin_nontemporal_store((i32x4_t){(int)pack2(h[0], h[1]), (int)pack2(h[2], h[3]), (int)pack2(h[4], h[5]), (int)pack2(h[6], h[7])}, reinterpret_cast<i32x4_t*>(line + e * 2));
+    __builtin_nontemporal_store((i32x2){(int)fp8x4_rt(v[0], v[1], v[2], v[3], lim8, inv8), (int)fp8x4_rt(v[4], v[5], v[6], v[7], lim8, inv8)}, reinterpret_cast<i32x2*>(line + 128 + e));
+    __builtin_nontemporal_store((i32x2){(int)fp8x4_rt(l[0], l[1], l[2], l[3], liml8, invl8), (int)fp8x4_rt(l[4], l[5], l[6], l[7], liml8, invl8)}, reinterpret_cast<i32x2*>(line + 192 + e));
     return;
   }
 #if AWT_GEMM_NT_STORE   // the planes are read next by another kernel, not by this one -> streaming stores (profiles/r03_gemm_experiments.txt)
@@ -1204,11 +1204,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(pp::Args g, GemmOut out
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wr = wave >> 2, wc = wave & 3, r32 = lane & 31, half = lane >> 5;
+  const int wr = wave >> 2, wc = wave & 3, r16 = lane & 15, kq = lane >> 4;
   float* patch = reinterpret_cast<float*>(smem + pp::PATCH_BASE + wave * 8192);
   const int c8 = (lane & 7) * 8, r8 = lane >> 3;
   constexpr bool SIDE = EPI == EPI_F32_RESID;
-  pp::kloop<pp::FMT_F16F8>(g, smem, [&](int tm, int tn, pp::Acc<pp::FMT_F16F8>& accs) {
+  pp::kloop<pp::FMT_F16F8S>(g, smem, [&](int tm, int tn, pp::Acc<pp::FMT_F16F8S>& accs) {
     auto& acc = accs.t;
     const int m0 = tm * pp::BM, n0 = tn * pp::BN;
     const int em0 = m0 + wr * 128, en = n0 + wc * 64 + c8;
@@ -1227,20 +1227,24 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(pp::Args g, GemmOut out
       if constexpr (SIDE) load_sides(side, 0);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
+        // strip i = the 16-row tiles 2 i, 2 i + 1 (C layout: column lane & 15, row 4 (lane >> 4) + reg).  Patch position of (row, col): the column rotated by
+        // 16 ((row >> 2) & 3) -- the four lane groups of one write then cover all 64 banks -- and XORed with 4 (row & 1) for the 16-byte reads below
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-          for (int rr = 0; rr < 16; ++rr) {
-            const int row = (rr & 3) + 8 * (rr >> 2) + 4 * half;
-            patch[row * 64 + ((j * 32 + r32) ^ ((row & 1) << 2))] = acc[i][j][rr];
-          }
+          for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+              const int row = rt * 16 + 4 * kq + reg;
+              patch[row * 64 + (((ct * 16 + r16 + 16 * kq) & 63) ^ ((reg & 1) << 2))] = acc[2 * i + rt][ct][reg];
+            }
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if constexpr (SIDE) { if (i + 1 < 4) load_sides(side_next, i + 1); }
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-          const int rl = r8 + 8 * it, sw = (rl & 1) << 2;
-          const float4 v0 = *reinterpret_cast<const float4*>(patch + rl * 64 + (c8 ^ sw)), v1 = *reinterpret_cast<const float4*>(patch + rl * 64 + ((c8 + 4) ^ sw));
+          const int rl = r8 + 8 * it, sw = (rl & 1) << 2, rot = 16 * ((rl >> 2) & 3);
+          const float4 v0 = *reinterpret_cast<const float4*>(patch + rl * 64 + (((c8 + rot) & 63) ^ sw)), v1 = *reinterpret_cast<const float4*>(patch + rl * 64 + (((c8 + 4 + rot) & 63) ^ sw));
           store_out8_f8<EPI, FULL, ILV>(out, em0 + i * 32 + rl, en, v0, v1, side[it][0], side[it][1], b0, b1, g.M);
         }
         if constexpr (SIDE) {
@@ -1644,7 +1648,7 @@ int launch_gemm_batched(awt_ctx* c, int batch, int M, int N, int K, const bf16_t
 // tuning knob "gemm_pp": 0 = off (default), 1 = automatic (large launches on weights that are not fp16-exact), 2 = wherever supported.
 // Measured on the headline step (profiles/r04_gemm_pp_encoder_ab.txt, interleaved A/B in one process): GEMM class 33.83 (shipped) vs 33.75 ms (mode 1),
 // LayerNorm + 0.57 ms (its interleaved-line stores): a tie, so the shipped two-workgroups-per-CU kernels stay the default.
-int g_pp_mode = 0;
+int g_pp_mode = 1;   // tuning knob "gemm_pp" (include/awt.h): 1 = automatic
 int awt_gemm_pp_mode() { return g_pp_mode; }
 void awt_gemm_set_pp_mode(int v) { g_pp_mode = v; }
 bool gemm_pp_supported(int M, int N, int K, int epi) {

@@ -104,12 +104,15 @@ def test_encoder_f16f8_on_the_ping_pong_gemm(name, trimmed, batch):
     mel = _mel(cfg, batch)
     enc = _native(cfg, "f16f8")
     x = torch.from_numpy(mel).cuda()
+    _lib.tuning_set("gemm_pp", 0)
     base = enc(x).last_hidden_state.cpu().numpy()
     _lib.tuning_set("gemm_pp", 2)
+    _lib.tuning_set("gemm_pp_mask", 15)
     try:
         out = enc(x).last_hidden_state.cpu().numpy()
     finally:
-        _lib.tuning_set("gemm_pp", 0)
+        _lib.tuning_set("gemm_pp", 1)
+        _lib.tuning_set("gemm_pp_mask", 12)
     ref = oracle_enc.encoder_forward(W, mel, cfg.heads).numpy()
     e = oracle_enc.error_norms(out, ref)
     print(name, trimmed, e, "vs the shipped tiling", float(np.abs(out - base).max()))

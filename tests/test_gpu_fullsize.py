@@ -41,6 +41,25 @@ def test_batch_permutation_and_chunking_are_exact(full):
     assert torch.equal(small_chunks.encode_pcm(pcm), hidden)                            # chunk size is invisible
 
 
+def test_ping_pong_mlp_route_is_bit_identical_to_the_128_row_tiles(full):
+    # at this size the f16f8 mode takes the persistent ping-pong GEMM for fc1 / fc2 ("gemm_pp" = 1, automatic): the same products in the same order as the
+    # 128 x 256 kernel's 16 x 16 form, so switching it off -- or on for all four projections -- must not change one bit of the hidden states
+    cfg, pcm, enc, hidden, feats = full
+    if enc.precision != "f16f8":
+        pytest.skip("the ping-pong GEMM is an f16f8 kernel")
+    from mlx8_ws_audio_transformer_amd import _lib
+    try:
+        _lib.tuning_set("gemm_pp", 0)
+        off = enc.encode_pcm(pcm)
+        _lib.tuning_set("gemm_pp", 2)
+        _lib.tuning_set("gemm_pp_mask", 15)
+        every = enc.encode_pcm(pcm)
+    finally:
+        _lib.tuning_set("gemm_pp", 1)
+        _lib.tuning_set("gemm_pp_mask", 12)
+    assert torch.equal(off, hidden) and torch.equal(every, hidden)
+
+
 def test_duplicate_and_silent_clips(full):
     cfg, pcm, enc, hidden, feats = full
     p2 = pcm.clone()
