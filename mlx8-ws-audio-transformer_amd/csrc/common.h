@@ -191,7 +191,23 @@ __device__ __forceinline__ float erf_fast(float x) {
   return copysignf(y, x);
 }
 // erf GELU (not the tanh form), as torch.nn.functional.gelu (HF:modeling_whisper.py:618-619, activation_function "gelu")
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f)); }
+// One transcendental instead of two (v_rcp_f32 and v_exp_f32 are quarter-rate; the GELU epilogue of fc1 is the largest block of vector work in the encoder step):
+// erfc(t) = 2^(-t q(t)) for t = |x| / sqrt 2 <= 4.2 with q a degree-6 polynomial -- a weighted minimax fit of -log2(erfc(t)) / t, |erf error| <= 1.6e-7 when
+// evaluated in fp32 (tools/fit_erfc_exp2.py; Abramowitz-Stegun 7.1.26 above: 1.5e-7) -- continued beyond 4.2 (erfc = 2.9e-9 there) along its tangent in the
+// exponent (slope 12.5 per unit of t: an upper bound of erfc that falls below 1e-30 by t = 10, so a large negative x gives -0 as it must), and
+// gelu(x) = x / 2 + |x| / 2 erf(|x| / sqrt 2) = (h + |h|) - |h| erfc(t),  h = x / 2.
+__device__ __forceinline__ float gelu_erf(float x) {
+  const float t = fabsf(x) * 0.70710678118654752440f, tc = fminf(t, 4.2f);
+  float q = fmaf(-0.00010022104106610641f, tc, 0.0004615735961124301f);
+  q = fmaf(q, tc, 0.0023022345267236233f);
+  q = fmaf(q, tc, -0.029452508315443993f);
+  q = fmaf(q, tc, 0.14896366000175476f);
+  q = fmaf(q, tc, 0.9183286428451538f);
+  q = fmaf(q, tc, 1.6279137134552002f);
+  const float e = __builtin_amdgcn_exp2f(fmaf(tc - t, 12.5f, -tc * q));
+  const float h = 0.5f * x;
+  return fmaf(-fabsf(h), e, h + fabsf(h));
+}
 
 // Fragment-major weight layout.  Every "W-side" GEMM operand is library-owned and static within a step, so it is stored
 // the way v_mfma_f32_16x16x32_bf16 consumes it: for each (16-row n-tile, 32-wide k-step) one contiguous 1 KB block holding

@@ -90,6 +90,12 @@ def test_cross_entropy_gelu_layernorm_and_embedding_ops():
     F.gelu(xd).backward(dy.double())
     assert (nd.gelu(x).double() - F.gelu(x.double())).abs().max().item() < 1e-6
     assert (nd.gelu_backward(x, dy).double() - xd.grad).abs().max().item() < 2e-6
+    # the one-transcendental erf GELU (common.h gelu_erf: erfc as 2^(poly)) over its whole domain: a dense grid through the fitted range, the tangent continuation
+    # beyond |x| / sqrt 2 = 4.2, and magnitudes where the negative branch has to underflow to zero rather than leave a residue
+    grid = torch.cat([torch.linspace(-12, 12, 200001), torch.tensor([0.0, -0.0, 1e-30, -1e-30, 5.94, -5.94, 6.5, -6.5, 40.0, -40.0, 1e4, -1e4, 6e4, -6e4, 3.0])]).cuda()      # 200016 values (the operator takes multiples of 4)
+    got, want = nd.gelu(grid).double(), F.gelu(grid.double())
+    assert ((got - want).abs() / grid.double().abs().clamp(min=1.0)).max().item() < 2.5e-7
+    assert (got[grid < -15] == 0).all() and torch.equal(got[grid > 15].float(), grid[grid > 15])
     g, b, dres = _rand((256,), 5) + 1.0, _rand((256,), 6), _rand((50, 256), 7)
     xd = x.double().requires_grad_(True)
     F.layer_norm(xd, (256,), g.double(), b.double(), 1e-5).backward(dy.double())
