@@ -491,7 +491,7 @@ def sweep_measure(a, R, shard, t_synth, with_cpu_baseline):
                        "mode": "trimmed (NOT reference-equivalent)" if a.trimmed else "parity (clip zero-padded to 30 s, as the reference computes)",
                        "clips_total": a.clips, "clips_this_rank": int(pcm.shape[0]), "batches_this_rank": nb, "tail_batch": int(pcm.shape[0] % a.batch),
                        "precision": a.precision, "weights": a.weights, "parallelism": "dp%d (contiguous clip shards, no data-path collective)" % R.world},
-            "roofline": {"bound": "mfma", "kernel": "gemm_f8_kernel / gemm_kernel<%s> (every encoder GEMM of rank 0's %d batches)" % (a.precision, nb),
+            "roofline": {"bound": "mfma", "kernel": "gemm_f8s_kernel / gemm_pp_kernel / gemm_f8_kernel / gemm_kernel<%s> (every encoder GEMM of rank 0's %d batches)" % (a.precision, nb),
                          "achieved": round(achieved, 2), "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_DENSE_TFLOPS, 4), "traffic": None,
                          "launches": gemm_n, "avg_launch_ms": round(gemm_ms / max(gemm_n, 1), 4), "gemm_ms_whole_set": round(gemm_ms, 1),
                          "note": "algorithmic FLOP = 2 M N K per launch; HIP events on the launch stream inside the timed region (rank 0)"},
@@ -752,7 +752,7 @@ def measure_encode(a, R, _lib, enc, pcm, kind):
                     else "the same initialisation rounded to fp16-representable values (a frozen base released in half precision)"),
         "fp16_exact_projection_matrices": "%d of %d (found by the library at upload)" % (n_exact, n_mat),
         "mfma_products_per_fragment_pair": round(terms, 3),
-        "roofline": {"bound": "mfma", "kernel": "gemm_f8_kernel / gemm_kernel<%s> (all encoder GEMMs: conv stem, QKV, out, fc1, fc2)" % enc.precision,
+        "roofline": {"bound": "mfma", "kernel": "gemm_f8s_kernel / gemm_pp_kernel / gemm_f8_kernel / gemm_kernel<%s> (all encoder GEMMs: conv stem, QKV, out, fc1, fc2)" % enc.precision,
                      "achieved": round(achieved, 2), "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / PEAK_BF16_DENSE_TFLOPS, 4), "traffic": None,
                      "launches": gemm_n, "avg_launch_ms": round(gemm_ms / max(gemm_n, 1), 4),

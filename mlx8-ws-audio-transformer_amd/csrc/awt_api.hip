@@ -61,6 +61,11 @@ extern "C" int awt_tuning_set(const char* key, int value) {
     g_pp_mask = value;
     return AWT_OK;
   }
+  if (!strcmp(key, "gemm_pp_stagger")) {
+    AWT_REQUIRE(value >= 0 && value <= 16, AWT_ERR_INVALID, "tuning_set: gemm_pp_stagger must be 0 (off) .. 16");
+    awt_gemm_set_pp_stagger(value);
+    return AWT_OK;
+  }
   if (!strcmp(key, "gemm_mfma16")) {
     AWT_REQUIRE(value == 0 || value == 1, AWT_ERR_INVALID, "tuning_set: gemm_mfma16 must be 1 (default: the f16f8 GEMM's 16 x 16 MFMA form where it applies) or 0 (32 x 32 only)");
     awt_gemm_set_mfma16(value);

@@ -1649,6 +1649,8 @@ int launch_gemm_batched(awt_ctx* c, int batch, int M, int N, int K, const bf16_t
 // Measured on the headline step (profiles/r04_gemm_pp_encoder_ab.txt, interleaved A/B in one process): GEMM class 33.83 (shipped) vs 33.75 ms (mode 1),
 // LayerNorm + 0.57 ms (its interleaved-line stores): a tie, so the shipped two-workgroups-per-CU kernels stay the default.
 int g_pp_mode = 1;   // tuning knob "gemm_pp" (include/awt.h): 1 = automatic
+int g_pp_stagger = 0;   // tuning knob "gemm_pp_stagger": start-up de-phasing of the persistent workgroups (gemm_pp.h Args::stagger), 0 = off
+void awt_gemm_set_pp_stagger(int v) { g_pp_stagger = v; }
 int awt_gemm_pp_mode() { return g_pp_mode; }
 void awt_gemm_set_pp_mode(int v) { g_pp_mode = v; }
 bool gemm_pp_supported(int M, int N, int K, int epi) {
@@ -1663,7 +1665,7 @@ int launch_gemm_pp(awt_ctx* c, int M, int N, const GemmSeg& seg, GemmEpilogue ep
   pp::Args a{};
   a.A = seg.a_ilv; a.a_row_bytes = (int64_t)seg.lda * 4; a.W = seg.w_pp;
   a.M = M; a.N = N; a.K = seg.K; a.nk = seg.K / 32;
-  a.tiles_m = (M + pp::BM - 1) / pp::BM; a.tiles_n = N / pp::BN; a.ntiles = a.tiles_m * a.tiles_n; a.gm = g_gm;
+  a.tiles_m = (M + pp::BM - 1) / pp::BM; a.tiles_n = N / pp::BN; a.ntiles = a.tiles_m * a.tiles_n; a.gm = g_gm; a.stagger = g_pp_stagger;
   static int n_cu[64] = {};
   int dev = 0; AWT_HIP_CHECK(hipGetDevice(&dev));
   if (!n_cu[dev & 63]) { hipDeviceProp_t p; AWT_HIP_CHECK(hipGetDeviceProperties(&p, dev)); n_cu[dev & 63] = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256; }

@@ -331,6 +331,20 @@ int main(int argc, char** argv) {
       CK(hipFree(A)); CK(hipFree(W)); CK(hipFree(C));
     }
   }
+  if (mode == "cus") {   // is the exposed store time a per-CU limit or a chip-wide (HBM) one?  The same GEMM on 256 / 128 / 64 persistent workgroups
+    const Problem p = {"fc1", M, 3072, 768};
+    char *A, *W; float* C;
+    prepare<pp::FMT_F16F8S>(p, A, W, 99);
+    CK(hipMalloc(&C, (size_t)p.M * p.N * 4));
+    const int ntiles = ((p.M + 255) / 256) * (p.N / 256);
+    for (int grid : {256, 128, 64, 32}) {
+      const float t0 = run<pp::FMT_F16F8S, 0>(p, A, W, C, 5, grid), t1 = run<pp::FMT_F16F8S, 1>(p, A, W, C, 5, grid);
+      const double tiles_per_wg = (double)ntiles / grid;
+      printf("cus   fc1 on %3d workgroups: K loops only %.3f ms, with fp32 stores %.3f ms -> %.2f us of exposed store time per 256 KB tile = %.1f GB/s per CU, %.2f TB/s chip-wide\n", grid, t0, t1,
+             (t1 - t0) * 1e3 / tiles_per_wg, 262144.0 / ((t1 - t0) * 1e-3 / tiles_per_wg) / 1e9, 262144.0 * grid / ((t1 - t0) * 1e-3 / tiles_per_wg) / 1e12);
+    }
+    CK(hipFree(A)); CK(hipFree(W)); CK(hipFree(C));
+  }
   if (mode == "ab" || mode == "all") {
     Awt L;
     if (L.open()) {

@@ -42,7 +42,7 @@ import csv, glob, json, sys, collections
 out, tag = sys.argv[1], sys.argv[2]
 sys.path.insert(0, "."); import bench
 def short(n):
-    for k, pats in (("gemm_kernel", ("gemm_kernel", "gemm_f8_kernel")), ("attention_kernel", ("attention_kernel", "attention_f16f8")), ("layernorm_kernel", ("layernorm_kernel",))):
+    for k, pats in (("gemm_kernel", ("gemm_kernel", "gemm_f8_kernel", "gemm_f8s_kernel", "gemm_pp_kernel")), ("attention_kernel", ("attention_kernel", "attention_f16f8")), ("layernorm_kernel", ("layernorm_kernel",))):
         if any(p in n for p in pats): return k
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
 for d in ("pmc_FABRIC_lat", "pmc_FABRIC_dram", "pmc_L2", "pmc_L2cyc"):
@@ -72,7 +72,7 @@ import csv, glob, json, sys, collections
 out, tag = sys.argv[1], sys.argv[2]
 sys.path.insert(0, "."); import bench
 def short(n):
-    for k, pats in (("gemm_kernel", ("gemm_kernel", "gemm_f8_kernel")), ("attention_kernel", ("attention_kernel", "attention_f16f8")), ("layernorm_kernel", ("layernorm_kernel",)),
+    for k, pats in (("gemm_kernel", ("gemm_kernel", "gemm_f8_kernel", "gemm_f8s_kernel", "gemm_pp_kernel")), ("attention_kernel", ("attention_kernel", "attention_f16f8")), ("layernorm_kernel", ("layernorm_kernel",)),
                     ("logmel_stage1", ("logmel_stage1",)), ("logmel_finalize", ("logmel_finalize",)), ("im2col", ("im2col",))):
         if any(p in n for p in pats): return k
 cc = glob.glob(f"{out}/pmc_MFMA/**/*counter_collection.csv", recursive=True)
@@ -104,7 +104,7 @@ import csv, glob, json, sys, collections
 out, tag = sys.argv[1], sys.argv[2]
 sys.path.insert(0, "."); import bench
 def short(n):
-    for k, pats in (("gemm_kernel", ("gemm_kernel", "gemm_f8_kernel")), ("attention_kernel", ("attention_kernel", "attention_f16f8")), ("layernorm_kernel", ("layernorm_kernel",)),
+    for k, pats in (("gemm_kernel", ("gemm_kernel", "gemm_f8_kernel", "gemm_f8s_kernel", "gemm_pp_kernel")), ("attention_kernel", ("attention_kernel", "attention_f16f8")), ("layernorm_kernel", ("layernorm_kernel",)),
                     ("logmel_stage1", ("logmel_stage1",)), ("logmel_finalize", ("logmel_finalize",)), ("im2col", ("im2col",))):
         if any(p in n for p in pats): return k
     return None
