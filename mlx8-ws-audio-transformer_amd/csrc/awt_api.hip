@@ -61,6 +61,11 @@ extern "C" int awt_tuning_set(const char* key, int value) {
     g_pp_mask = value;
     return AWT_OK;
   }
+  if (!strcmp(key, "gemm_pp_dma_waves")) {
+    AWT_REQUIRE(value == 8 || value == 2, AWT_ERR_INVALID, "tuning_set: gemm_pp_dma_waves must be 8 (every wave stages) or 2 (waves 6 and 7 stage)");
+    awt_gemm_set_pp_dma_waves(value);
+    return AWT_OK;
+  }
   if (!strcmp(key, "gemm_pp_stagger")) {
     AWT_REQUIRE(value >= 0 && value <= 16, AWT_ERR_INVALID, "tuning_set: gemm_pp_stagger must be 0 (off) .. 16");
     awt_gemm_set_pp_stagger(value);

@@ -385,6 +385,7 @@ int launch_pack_weight_pp(awt_ctx* c, const float* src, int N, int K, int row_of
 int awt_gemm_pp_mode();                             // tuning knob "gemm_pp": 0 off (default), 1 automatic, 2 wherever supported
 void awt_gemm_set_pp_mode(int v);
 void awt_gemm_set_pp_stagger(int v);
+void awt_gemm_set_pp_dma_waves(int v);
 void awt_gemm_set_mfma16(int v);                    // tuning knob "gemm_mfma16": 1 (default) = the 16 x 16 MFMA form of the f16f8 GEMM wherever its weight copies exist, 0 = off
 
 // out_f32 (the final layer_norm) or operand planes of precision `prec`

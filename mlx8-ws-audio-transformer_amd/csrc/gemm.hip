@@ -1199,7 +1199,7 @@ int launch_f8(GemmArgs a, hipStream_t s) {
 // The epilogue is the one above (per-wave LDS transposition of 32 x 64 strips, eight columns per lane, whole row segments per store),
 // with the patch in the wave's 8 KB of the last 64 KB of LDS (pitch 64 floats, 16-byte groups XOR-ed by the row's parity against
 // bank conflicts on the transposed read) and its stores left in flight while the next tile's K loop starts.
-template <int EPI, bool ILV>
+template <int EPI, bool ILV, int DMAW>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(pp::Args g, GemmOut out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -1208,7 +1208,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(pp::Args g, GemmOut out
   float* patch = reinterpret_cast<float*>(smem + pp::PATCH_BASE + wave * 8192);
   const int c8 = (lane & 7) * 8, r8 = lane >> 3;
   constexpr bool SIDE = EPI == EPI_F32_RESID;
-  pp::kloop<pp::FMT_F16F8S>(g, smem, [&](int tm, int tn, pp::Acc<pp::FMT_F16F8S>& accs) {
+  pp::kloop<pp::FMT_F16F8S, DMAW>(g, smem, [&](int tm, int tn, pp::Acc<pp::FMT_F16F8S>& accs) {
     auto& acc = accs.t;
     const int m0 = tm * pp::BM, n0 = tn * pp::BN;
     const int em0 = m0 + wr * 128, en = n0 + wc * 64 + c8;
@@ -1259,10 +1259,17 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(pp::Args g, GemmOut out
   });
 }
 
+int g_pp_dma_waves = 8;   // tuning knob "gemm_pp_dma_waves": 8 = every wave stages (default), 2 = waves 6 and 7 stage for the workgroup (gemm_pp.h DMA_WAVES)
 template <int EPI, bool ILV>
 int launch_pp(const pp::Args& a, const GemmOut& o, int grid, hipStream_t s) {
-  AWT_ONCE_PER_DEVICE(AWT_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI, ILV>, hipFuncAttributeMaxDynamicSharedMemorySize, pp::LDS_BYTES)));
-  hipLaunchKernelGGL((gemm_pp_kernel<EPI, ILV>), dim3(grid), dim3(pp::NT), pp::LDS_BYTES, s, a, o);
+  if (g_pp_dma_waves == 2) {
+    AWT_ONCE_PER_DEVICE(AWT_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI, ILV, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, pp::LDS_BYTES)));
+    hipLaunchKernelGGL((gemm_pp_kernel<EPI, ILV, 2>), dim3(grid), dim3(pp::NT), pp::LDS_BYTES, s, a, o);
+    AWT_HIP_CHECK(hipGetLastError());
+    return AWT_OK;
+  }
+  AWT_ONCE_PER_DEVICE(AWT_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI, ILV, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, pp::LDS_BYTES)));
+  hipLaunchKernelGGL((gemm_pp_kernel<EPI, ILV, 8>), dim3(grid), dim3(pp::NT), pp::LDS_BYTES, s, a, o);
   AWT_HIP_CHECK(hipGetLastError());
   return AWT_OK;
 }
@@ -1683,6 +1690,7 @@ int launch_gemm_pp(awt_ctx* c, int M, int N, const GemmSeg& seg, GemmEpilogue ep
 }
 
 void awt_gemm_set_mfma16(int v) { g_mfma16 = v; }
+void awt_gemm_set_pp_dma_waves(int v) { g_pp_dma_waves = v; }
 void awt_gemm_force_tile(int t) { g_force_tile = t; }
 void awt_gemm_set_gm(int v) { g_gm = v > 0 ? v : AWT_GEMM_GM; }
 

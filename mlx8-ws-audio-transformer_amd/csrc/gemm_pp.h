@@ -122,8 +122,9 @@ __device__ __forceinline__ void mfma_y(ACC& c, bf16x8 a0, bf16x8 a1, bf16x8 b0, 
 // in flight (they are older than every DMA the loop waits for afterwards: vmcnt retires in order, so the loop's counted waits then
 // wait for them as well -- the price of a store burst is paid at the next tile's first waits, not before its first MFMAs).
 // Requirements: nk even and >= 4; A readable for tiles_m * 256 rows (rows >= M feed accumulators that are never stored).
-template <int FMT, class EPI>
+template <int FMT, int DMA_WAVES = 8, class EPI>
 __device__ __forceinline__ void kloop(const Args& g, char* smem, EPI&& epi) {
+  static_assert(DMA_WAVES == 8 || DMA_WAVES == 2, "staging by all eight waves or by waves 6 and 7");
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wr = wave >> 2, wc = wave & 3;
@@ -153,31 +154,46 @@ __device__ __forceinline__ void kloop(const Args& g, char* smem, EPI&& epi) {
   // ---- operand streams.  Every region type walks the same sequence of (tile, K-tile) pairs at its own phase; inside a tile a stream
   // advances by one K-tile per staging (A: 128 bytes along the row, W: 2 regions), and all four streams move on to the next tile within
   // the tile's last K-tile pair, at fixed points of the schedule (pair<true> below), to bases computed once per tile.
+  // DMA_WAVES = 8: every wave stages two 1 KB pieces of each region.  DMA_WAVES = 2: waves 6 and 7 stage eight pieces each and are the only waves that ever wait
+  // on vmcnt in the loop -- the other six waves' epilogue stores then drain behind the next tile's K loop instead of in front of its first DMA waits (vmcnt
+  // retires in order, so a wave that stores AND stages has to see its stores acknowledged before the DMA it is waiting for).
+  constexpr int PIECES = 16 / DMA_WAVES;                  // 1 KB pieces of a 16 KB region per staging wave
+  const bool dma_wave = wave >= 8 - DMA_WAVES;
+  const int dw = wave - (8 - DMA_WAVES);                 // index among the staging waves
   const char* ab[2];                                     // wave-uniform: A + (tile row + s * 64) * row bytes + K-tile * 128
   const char* wb[2];                                     // wave-uniform: W region (tile column, K-tile, s)
-  unsigned aoff[2];                                      // per lane: piece i of the wave: row (rho >> 6) * 128 + (rho & 63), chunk (lane & 7) ^ f(rho)
+  // per lane: piece p = dw * PIECES + i covers region rows rho = 8 p + (lane >> 3) = source rows (rho >> 6) * 128 + (rho & 63), chunk (lane & 7) ^ ((rho >> 1) & 7).
+  // Consecutive pieces are 8 rows apart (a wave-uniform address step; PIECES <= 8 keeps a wave inside one 64-row half) and flip bit 2 of the swizzle: two offsets.
+  unsigned aoff[2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int rho = wave * 16 + i * 8 + (lane >> 3), c = (lane & 7) ^ ((rho >> 1) & 7);
-    aoff[i] = (unsigned)(((rho >> 6) * 128 + (rho & 63)) * g.a_row_bytes + c * 16);
+  for (int e = 0; e < 2; ++e) {
+    const int rho = (dw * PIECES + e) * 8 + (lane >> 3), c = (lane & 7) ^ ((rho >> 1) & 7);
+    aoff[e] = (unsigned)(((rho >> 6) * 128 + (rho & 63) - 8 * e) * g.a_row_bytes + c * 16);     // piece i: + 8 i rows on the scalar base
   }
-  const unsigned wvoff = wave * 2048 + lane * 16;
+  const unsigned wvoff = lane * 16;
   auto a_base = [&](int tm, int s) { return g.A + ((int64_t)tm * BM + s * 64) * g.a_row_bytes; };
   auto w_base = [&](int tn, int s) { return g.W + w_region_offset(tn, 0, s, nk); };
   auto stage_a = [&](auto s_t, auto buf_t) {
     constexpr int s = decltype(s_t)::value, buf = decltype(buf_t)::value;
-    const unsigned dst = lds0 + buf * BUF + (s ? OFF_A1 : OFF_A0) + wave * 2048;
-    dma_s(ab[s], aoff[0], __builtin_amdgcn_readfirstlane(dst));
-    dma_s(ab[s], aoff[1], __builtin_amdgcn_readfirstlane(dst + 1024));
+    if (dma_wave) {
+      const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + buf * BUF + (s ? OFF_A1 : OFF_A0) + dw * PIECES * 1024);
+#pragma unroll
+      for (int i = 0; i < PIECES; ++i) dma_s(ab[s] + (int64_t)(8 * i) * g.a_row_bytes, aoff[i & 1], dst + i * 1024);
+    }
     ab[s] += 128;
   };
   auto stage_b = [&](auto s_t, auto buf_t) {
     constexpr int s = decltype(s_t)::value, buf = decltype(buf_t)::value;
-    const unsigned dst = lds0 + buf * BUF + (s ? OFF_B1 : OFF_B0) + wave * 2048;
-    dma_s(wb[s], wvoff, __builtin_amdgcn_readfirstlane(dst));
-    dma_s(wb[s], wvoff + 1024, __builtin_amdgcn_readfirstlane(dst + 1024));
+    if (dma_wave) {
+      const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + buf * BUF + (s ? OFF_B1 : OFF_B0) + dw * PIECES * 1024);
+#pragma unroll
+      for (int i = 0; i < PIECES; ++i) dma_s(wb[s] + (dw * PIECES + i) * 1024, wvoff, dst + i * 1024);
+    }
     wb[s] += 2 * REGION;
   };
+  // counted waits of the staging waves: N regions still in flight = N * PIECES pieces (the other waves have nothing of the loop's to wait for)
+  auto vmw = [&](auto n_t) { if (dma_wave) vmwait<decltype(n_t)::value * PIECES>(); };
+  using R5 = std::integral_constant<int, 5>; using R4 = std::integral_constant<int, 4>;
   using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
 
   // ---- fragment read addresses of the CURRENT K-tile buffer (flipped once per K-tile; a ds_read's 16-bit immediate holds the region
@@ -300,7 +316,7 @@ __device__ __forceinline__ void kloop(const Args& g, char* smem, EPI&& epi) {
   // ---- prologue: B0, A0, B1, A1 of K-tile 0 and B0, A0 of K-tile 1
   stage_b(I0{}, I0{}); stage_a(I0{}, I0{}); stage_b(I1{}, I0{}); stage_a(I1{}, I0{});
   stage_b(I0{}, I1{}); stage_a(I0{}, I1{});
-  vmwait<8>();          // B0(0), A0(0) have landed (this wave's pieces)
+  vmw(R4{});            // B0(0), A0(0) have landed (this wave's pieces): four of the six regions requested may still be in flight
   bar();
 
   FragA<FMT> ra; FragB<FMT> rba, rbb;
@@ -309,29 +325,29 @@ __device__ __forceinline__ void kloop(const Args& g, char* smem, EPI&& epi) {
   auto pair = [&](auto last_t) {
     constexpr bool LAST = decltype(last_t)::value;
     // ================= even K-tile (buffer 0): B0 is in rba
-    read_a(I0{}, ra, I0{}); stage_a(I1{}, I1{}); vmwait<10>(); bar();
+    read_a(I0{}, ra, I0{}); stage_a(I1{}, I1{}); vmw(R5{}); bar();
     lgkm0(); tie(ra); tie(rba); mma(I0{}, I0{}, ra, rba, I0{}); bar();
     if constexpr (LAST) wb[0] = w_base(tn1, 0);
-    read_b(I1{}, rbb, I0{}); stage_b(I0{}, I0{}); vmwait<10>(); bar();
+    read_b(I1{}, rbb, I0{}); stage_b(I0{}, I0{}); vmw(R5{}); bar();
     lgkm0(); tie(rbb); mma(I0{}, I1{}, ra, rbb, I0{}); bar();
     if constexpr (LAST) ab[0] = a_base(tm1, 0);
-    read_a(I1{}, ra, I0{}); stage_a(I0{}, I0{}); vmwait<10>(); bar();
+    read_a(I1{}, ra, I0{}); stage_a(I0{}, I0{}); vmw(R5{}); bar();
     lgkm0(); tie(ra); mma(I1{}, I1{}, ra, rbb, I0{}); bar();
     if constexpr (LAST) wb[1] = w_base(tn1, 1);
     flip();
-    read_b(I0{}, rbb, I1{}); stage_b(I1{}, I0{}); vmwait<8>(); bar();          // next K-tile's B0 (buffer 1) into the set M3 just released
+    read_b(I0{}, rbb, I1{}); stage_b(I1{}, I0{}); vmw(R4{}); bar();          // next K-tile's B0 (buffer 1) into the set M3 just released
     mma(I1{}, I0{}, ra, rba, I0{}); bar();
     // ================= odd K-tile (buffer 1): B0 is in rbb
     if constexpr (LAST) ab[1] = a_base(tm1, 1);
-    read_a(I0{}, ra, I1{}); stage_a(I1{}, I0{}); vmwait<10>(); bar();
+    read_a(I0{}, ra, I1{}); stage_a(I1{}, I0{}); vmw(R5{}); bar();
     lgkm0(); tie(ra); tie(rbb); mma(I0{}, I0{}, ra, rbb, I1{}); bar();
-    read_b(I1{}, rba, I1{}); stage_b(I0{}, I1{}); vmwait<10>(); bar();
+    read_b(I1{}, rba, I1{}); stage_b(I0{}, I1{}); vmw(R5{}); bar();
     lgkm0(); tie(rba); mma(I0{}, I1{}, ra, rba, I1{}); bar();
-    read_a(I1{}, ra, I1{}); stage_a(I0{}, I1{}); vmwait<10>(); bar();
+    read_a(I1{}, ra, I1{}); stage_a(I0{}, I1{}); vmw(R5{}); bar();
     lgkm0(); tie(ra); mma(I1{}, I1{}, ra, rba, I1{}); bar();
     flip();
     if constexpr (!LAST) { read_b(I0{}, rba, I0{}); stage_b(I1{}, I1{}); }
-    vmwait<8>(); bar();
+    vmw(R4{}); bar();
     mma(I1{}, I0{}, ra, rbb, I1{}); bar();
   };
 

@@ -46,8 +46,12 @@ def test_linear_ping_pong(M, N, K):
     try:
         y = ops.linear(x, w, b, "f16f8")
         y2 = ops.linear(x, w, b, "f16f8")
+        _lib.tuning_set("gemm_pp_dma_waves", 2)          # waves 6 and 7 stage for the workgroup: another staging schedule, the same arithmetic
+        y3 = ops.linear(x, w, b, "f16f8")
     finally:
+        _lib.tuning_set("gemm_pp_dma_waves", 8)
         _lib.tuning_set("gemm_pp", 1)
+    assert torch.equal(y, y3)
     err = (y.double() - ref).abs().max().item()
     print((M, N, K), "ping-pong max-abs", err, "shipped kernel", (y_ship.double() - ref).abs().max().item())
     assert err < TOL["f16f8"] * max(1.0, ref.abs().max().item()), err

@@ -15,6 +15,9 @@
 #include <algorithm>
 #include "../mlx8-ws-audio-transformer_amd/csrc/gemm_pp.h"
 
+#ifndef PP_DMAW
+#define PP_DMAW 8      // -DPP_DMAW=2: waves 6 and 7 stage for the workgroup (gemm_pp.h DMA_WAVES)
+#endif
 void awt_set_error(const std::string&) {}
 int awt_fail(int code, const std::string& m) { fprintf(stderr, "awt_fail: %s\n", m.c_str()); return code; }
 
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_test(pp::Args g, TestOut o) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wr = wave >> 2, wc = wave & 3;
   unsigned long long t0 = 0, r0 = 0;
   if constexpr (EPI == 2) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
-  pp::kloop<FMT>(g, smem, [&](int tm, int tn, pp::Acc<FMT>& accs) {
+  pp::kloop<FMT, PP_DMAW>(g, smem, [&](int tm, int tn, pp::Acc<FMT>& accs) {
     auto& acc = accs.t;
     if constexpr (EPI == 0 || EPI == 2 || pp::tiles16(FMT)) {
       float s = 0.f;
