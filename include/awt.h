@@ -339,6 +339,8 @@ int awt_op_attention_small_backward_dropout(awt_ctx* c, const float* q, int ldq,
  * awt_op_linear).  "gemm_pp_mask": which projections of a layer may take it, a bit set (1 qkv, 2 out_proj, 4 fc1, 8 fc2; fc2 only with
  * fc1; default 12 = the MLP pair, where it is measurably ahead).  Same products and the same accumulation order per output as the
  * 128 x 256 kernel's 16 x 16 form: bit-identical results where both apply.
+ * "gemm_pp_stagger": start-up de-phasing of the persistent workgroups in sixteenths of a tile's K loop per group of CUs (0 = off, default;
+ * measured: no gain, profiles/r04_gemm_pp16_epilogue.txt).
  * "gemm_mfma16": 1 (default) = the 128 x 256 f16f8 GEMM issues its products as 16 x 16 MFMAs (both e4m3 cross terms in one block-scaled
  * instruction), 0 = the 32 x 32 form (results differ by the fp32 summation order only). */
 int awt_tuning_set(const char* key, int value);

@@ -38,7 +38,7 @@ struct Attn8Args {
   bf16_t* o16; uint8_t *o8, *ol8; float* o_f32;  // output: f16f8 activation planes [B*S, H*64] or fp32
   float* lse;
   int B, H, S;
-  char* o_ilv;                                   // ... or the same activation as interleaved lines (common.h Act::ilv), when set
+  char* o_ilv;                                   // ... or the same activation as split lines (common.h Act::ilv), when set
 };
 
 __device__ __forceinline__ int swz16(int row) { return (row >> 1) & 7; }        // K fp16 plane: 128-byte rows, 8 chunks, read by ds_read_b128 (32 distinct rows per chunk column)

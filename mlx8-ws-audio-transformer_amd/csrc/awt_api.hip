@@ -61,11 +61,6 @@ extern "C" int awt_tuning_set(const char* key, int value) {
     g_pp_mask = value;
     return AWT_OK;
   }
-  if (!strcmp(key, "gemm_pp_dma_waves")) {
-    AWT_REQUIRE(value == 8 || value == 2, AWT_ERR_INVALID, "tuning_set: gemm_pp_dma_waves must be 8 (every wave stages) or 2 (waves 6 and 7 stage)");
-    awt_gemm_set_pp_dma_waves(value);
-    return AWT_OK;
-  }
   if (!strcmp(key, "gemm_pp_stagger")) {
     AWT_REQUIRE(value >= 0 && value <= 16, AWT_ERR_INVALID, "tuning_set: gemm_pp_stagger must be 0 (off) .. 16");
     awt_gemm_set_pp_stagger(value);
@@ -329,7 +324,7 @@ Act act_offset(const Act& a, int64_t elems) {
   return r;
 }
 void set_out(GemmOut& o, const Act& a) { o.hi = a.p16; o.lo = a.lo16; o.hi8 = a.hi8; o.lo8 = a.lo8; o.ilv = a.ilv; }
-// the same buffer pair as one interleaved-line image (Act::ilv): the two 2-byte planes are adjacent, 4 bytes per element in all
+// the same buffer pair as one split-line image (Act::ilv): the two 2-byte planes are adjacent, 4 bytes per element in all
 Act make_ilv(bf16_t* p0) { Act a; a.ilv = (char*)p0; return a; }
 
 GemmSeg seg_plain(const Act& a, int64_t lda, const Planes& w, int64_t wcol, int K, int M) {
@@ -371,7 +366,7 @@ int linear_with_lora(awt_encoder* e, bf16_t* const u[2], bf16_t* const in[2], in
   return launch_gemm(e->ctx, M, lin.N, segs, nseg, terms, epi, out, s);
 }
 
-// y = x W^T on the persistent ping-pong kernel: x as interleaved lines (make_ilv), W's packed image; no adapter
+// y = x W^T on the persistent ping-pong kernel: x as split lines (make_ilv), W's packed image; no adapter
 int linear_pp(awt_encoder* e, bf16_t* in0, const Linear& lin, int M, GemmEpilogue epi, GemmOut out, hipStream_t s) {
   GemmSeg sg = seg_plain(make_ilv(in0), lin.K, lin.w, 0, lin.K, M);
   out.bias = lin.bias;
@@ -475,7 +470,7 @@ int encoder_layer(awt_encoder* e, Layer& L, const LayerBufs& b, int Bc, bool sav
   const int S = c.n_ctx, d = c.d_model, f = c.ffn_dim, H = c.n_heads, terms = e->prec;
   const int M = Bc * S;
   const int64_t plane = (int64_t)M * d;
-  // which of the four linears run on the persistent ping-pong kernel (inference only): their inputs are then written as interleaved lines by the
+  // which of the four linears run on the persistent ping-pong kernel (inference only): their inputs are then written as split lines by the
   // producer (LayerNorm, the attention epilogue, fc1's GELU epilogue) instead of as three planes -- same bytes, same buffers
   const bool pp_qkv = !save && (g_pp_mask & 1) && use_pp(e, L.qkv, L.lq, M, EPI_QKV), pp_out = !save && (g_pp_mask & 2) && use_pp(e, L.out, L.lo_, M, EPI_F32_RESID);
   const bool pp_fc1 = !save && (g_pp_mask & 4) && use_pp(e, L.fc1, L.l1, M, EPI_BF16_GELU), pp_fc2 = pp_fc1 && (g_pp_mask & 8) && use_pp(e, L.fc2, L.l2, M, EPI_F32_RESID);
@@ -844,7 +839,7 @@ extern "C" int awt_op_linear(awt_ctx* c, const float* x, const float* w, const f
 #endif
   }
   if (terms == PREC_F16F8 && awt_gemm_pp_mode() == 2 && gemm_pp_supported(M, N, K, EPI_F32)) {
-    // the persistent ping-pong kernel (tuning knob "gemm_pp" = 2): x as interleaved lines over the two x planes' space (its 256-row panel reads beyond M
+    // the persistent ping-pong kernel (tuning knob "gemm_pp" = 2): x as split lines over the two x planes' space (its 256-row panel reads beyond M
     // stay inside the workspace: the packed weight image of N >= 256 rows follows), the weight in the packed region image over the two w planes' space
     Act ai; ai.ilv = (char*)xh;
     int rcp = launch_split_planes(c, x, (int64_t)M * K, 1.0f, terms, kF8Act, nullptr, nullptr, nullptr, nullptr, s, ai.ilv); if (rcp) return rcp;

@@ -333,7 +333,7 @@ struct GemmSeg {
   // with the same lda, weights in w8_index order; w_ksteps / w_k0 still count 32-deep steps of the matrix / of the segment start)
   const uint8_t* a8; const uint8_t* al8; const uint8_t* w8; const uint8_t* wl8;
   int w_exact16;                                         // PREC_F16F8: every weight of the segment is exactly representable in fp16 (its lo8 image is zero)
-  // ping-pong kernel (launch_gemm_pp, PREC_F16F8): the activation as interleaved lines (Act::ilv, row pitch lda * 4 bytes) and the weight matrix in
+  // ping-pong kernel (launch_gemm_pp, PREC_F16F8): the activation as split lines (Act::ilv, row pitch lda * 4 bytes) and the weight matrix in
   // the packed region image of gemm_pp.h (launch_pack_weight_pp); both null = the segment is only for the kernels above
   const char* a_ilv; const char* w_pp;
   // 16 x 16 MFMA form (gemm_f8s_kernel, PREC_F16F8): the same weight matrix as 16-row fragment-major copies -- fp16 in w_frag_index order, the two e4m3
@@ -360,7 +360,7 @@ struct GemmOut {
   float* f32; const float* resid; int64_t ldo;
   bf16_t* hi; bf16_t* lo;                 // lo may be null when terms == 1
   uint8_t* hi8; uint8_t* lo8;             // PREC_F16F8: the e4m3 planes of the output (hi = its fp16 plane); same offsets as hi
-  char* ilv;                              // PREC_F16F8, EPI_BF16 / EPI_BF16_GELU of launch_gemm_pp: the output as interleaved lines instead (Act::ilv; dense [M][ldo])
+  char* ilv;                              // PREC_F16F8, EPI_BF16 / EPI_BF16_GELU of launch_gemm_pp: the output as split lines instead (Act::ilv; dense [M][ldo])
   bf16_t* hi2; bf16_t* lo2;               // EPI_BF16_GELU_SAVE: pre-activation planes (same ldo)
   const bf16_t* pre_hi; const bf16_t* pre_lo;   // EPI_BF16_DGELU: saved pre-activation planes (same ldo)
   const float* bias;                      // [N] or null
@@ -385,7 +385,6 @@ int launch_pack_weight_pp(awt_ctx* c, const float* src, int N, int K, int row_of
 int awt_gemm_pp_mode();                             // tuning knob "gemm_pp": 0 off (default), 1 automatic, 2 wherever supported
 void awt_gemm_set_pp_mode(int v);
 void awt_gemm_set_pp_stagger(int v);
-void awt_gemm_set_pp_dma_waves(int v);
 void awt_gemm_set_mfma16(int v);                    // tuning knob "gemm_mfma16": 1 (default) = the 16 x 16 MFMA form of the f16f8 GEMM wherever its weight copies exist, 0 = off
 
 // out_f32 (the final layer_norm) or operand planes of precision `prec`
@@ -400,9 +399,9 @@ int launch_split_f32(awt_ctx* c, const float* x, int64_t n, float scale, bf16_t*
 // lo8 = e4m3((x - fp16(x)) 2^(f8_exp + 11))
 struct F8Planes { bf16_t* p16; uint8_t* hi8; uint8_t* lo8; };
 int launch_split_planes(awt_ctx* c, const float* x, int64_t n, float scale, int prec, int f8_exp, bf16_t* p16, bf16_t* lo16, uint8_t* hi8,
-                        uint8_t* lo8, hipStream_t s, char* ilv = nullptr);   // ilv (PREC_F16F8, f8_exp == kF8Act): interleaved lines instead of the planes
+                        uint8_t* lo8, hipStream_t s, char* ilv = nullptr);   // ilv (PREC_F16F8, f8_exp == kF8Act): split lines instead of the planes
 int launch_attention_f16f8(awt_ctx* c, const F8Planes& q, const F8Planes& k, const F8Planes& v, const F8Planes& o, float* o_f32,
-                           float* lse, int B, int H, int S, hipStream_t s, char* o_ilv = nullptr);   // o_ilv: the output as interleaved lines (Act::ilv) instead of o
+                           float* lse, int B, int H, int S, hipStream_t s, char* o_ilv = nullptr);   // o_ilv: the output as split lines (Act::ilv) instead of o
 // weights: dst(row_off + n, col_off + k) = scale * src[n, c, dt], k = dt * C + c (taps = 1: plain [N, C]); dst is a
 // fragment-major matrix with ld / 32 k-steps (ld = its K, a multiple of 32; its row count a multiple of 16)
 // prec PREC_F16F8: hi = fp16 plane (w16f8_index order), lo = the hi8 plane, lo8 = the lo8 plane (w8_index order); else hi / lo in

@@ -1199,7 +1199,7 @@ int launch_f8(GemmArgs a, hipStream_t s) {
 // The epilogue is the one above (per-wave LDS transposition of 32 x 64 strips, eight columns per lane, whole row segments per store),
 // with the patch in the wave's 8 KB of the last 64 KB of LDS (pitch 64 floats, 16-byte groups XOR-ed by the row's parity against
 // bank conflicts on the transposed read) and its stores left in flight while the next tile's K loop starts.
-template <int EPI, bool ILV, int DMAW>
+template <int EPI, bool ILV>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(pp::Args g, GemmOut out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -1208,7 +1208,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(pp::Args g, GemmOut out
   float* patch = reinterpret_cast<float*>(smem + pp::PATCH_BASE + wave * 8192);
   const int c8 = (lane & 7) * 8, r8 = lane >> 3;
   constexpr bool SIDE = EPI == EPI_F32_RESID;
-  pp::kloop<pp::FMT_F16F8S, DMAW>(g, smem, [&](int tm, int tn, pp::Acc<pp::FMT_F16F8S>& accs) {
+  pp::kloop<pp::FMT_F16F8S>(g, smem, [&](int tm, int tn, pp::Acc<pp::FMT_F16F8S>& accs) {
     auto& acc = accs.t;
     const int m0 = tm * pp::BM, n0 = tn * pp::BN;
     const int em0 = m0 + wr * 128, en = n0 + wc * 64 + c8;
@@ -1259,17 +1259,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(pp::Args g, GemmOut out
   });
 }
 
-int g_pp_dma_waves = 8;   // tuning knob "gemm_pp_dma_waves": 8 = every wave stages (default), 2 = waves 6 and 7 stage for the workgroup (gemm_pp.h DMA_WAVES)
 template <int EPI, bool ILV>
 int launch_pp(const pp::Args& a, const GemmOut& o, int grid, hipStream_t s) {
-  if (g_pp_dma_waves == 2) {
-    AWT_ONCE_PER_DEVICE(AWT_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI, ILV, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, pp::LDS_BYTES)));
-    hipLaunchKernelGGL((gemm_pp_kernel<EPI, ILV, 2>), dim3(grid), dim3(pp::NT), pp::LDS_BYTES, s, a, o);
-    AWT_HIP_CHECK(hipGetLastError());
-    return AWT_OK;
-  }
-  AWT_ONCE_PER_DEVICE(AWT_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI, ILV, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, pp::LDS_BYTES)));
-  hipLaunchKernelGGL((gemm_pp_kernel<EPI, ILV, 8>), dim3(grid), dim3(pp::NT), pp::LDS_BYTES, s, a, o);
+  AWT_ONCE_PER_DEVICE(AWT_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI, ILV>, hipFuncAttributeMaxDynamicSharedMemorySize, pp::LDS_BYTES)));
+  hipLaunchKernelGGL((gemm_pp_kernel<EPI, ILV>), dim3(grid), dim3(pp::NT), pp::LDS_BYTES, s, a, o);
   AWT_HIP_CHECK(hipGetLastError());
   return AWT_OK;
 }
@@ -1652,10 +1645,10 @@ int launch_gemm_batched(awt_ctx* c, int batch, int M, int N, int K, const bf16_t
   return resid ? launch_batched_epi<EPI_F32_RESID>(a, batch, s) : launch_batched_epi<EPI_F32>(a, batch, s);
 }
 
-// tuning knob "gemm_pp": 0 = off (default), 1 = automatic (large launches on weights that are not fp16-exact), 2 = wherever supported.
-// Measured on the headline step (profiles/r04_gemm_pp_encoder_ab.txt, interleaved A/B in one process): GEMM class 33.83 (shipped) vs 33.75 ms (mode 1),
-// LayerNorm + 0.57 ms (its interleaved-line stores): a tie, so the shipped two-workgroups-per-CU kernels stay the default.
-int g_pp_mode = 1;   // tuning knob "gemm_pp" (include/awt.h): 1 = automatic
+// tuning knob "gemm_pp" (include/awt.h): 0 = off, 1 = automatic (default: large inference launches on weights that are not fp16-exact, for the projections in
+// awt_api.hip's gemm_pp_mask), 2 = wherever supported.  Measured on the headline step (profiles/r04_gemm_pp16_masks.txt, A/B interleaved in one process): the MLP
+// pair on this kernel 46.98 ms per step against 47.50 on the 128 x 256 kernel, QKV + out_proj neutral.
+int g_pp_mode = 1;
 int g_pp_stagger = 0;   // tuning knob "gemm_pp_stagger": start-up de-phasing of the persistent workgroups (gemm_pp.h Args::stagger), 0 = off
 void awt_gemm_set_pp_stagger(int v) { g_pp_stagger = v; }
 int awt_gemm_pp_mode() { return g_pp_mode; }
@@ -1667,8 +1660,8 @@ bool gemm_pp_supported(int M, int N, int K, int epi) {
 int launch_gemm_pp(awt_ctx* c, int M, int N, const GemmSeg& seg, GemmEpilogue epi, const GemmOut& out, hipStream_t s) {
   AWT_REQUIRE(c && gemm_pp_supported(M, N, seg.K, epi), AWT_ERR_INVALID, "gemm (ping-pong): N % 256 == 0, K % 64 == 0, K >= 128 and a supported epilogue required");
   AWT_REQUIRE(seg.a_ilv && seg.w_pp && seg.rows_out == M && seg.rows_in == M && seg.row_mul == 1 && seg.row_add == 0 && seg.w_k0 == 0 && seg.w_ksteps == seg.K / 32 && seg.lda == seg.K,
-              AWT_ERR_INVALID, "gemm (ping-pong): one plain, dense K segment over interleaved-line activations and a packed weight image");
-  AWT_REQUIRE(!out.ilv || ((epi == EPI_BF16 || epi == EPI_BF16_GELU) && out.ldo == N && out.n_valid == N), AWT_ERR_INVALID, "gemm (ping-pong): an interleaved-line output is a dense [M, N] activation");
+              AWT_ERR_INVALID, "gemm (ping-pong): one plain, dense K segment over split-line activations and a packed weight image");
+  AWT_REQUIRE(!out.ilv || ((epi == EPI_BF16 || epi == EPI_BF16_GELU) && out.ldo == N && out.n_valid == N), AWT_ERR_INVALID, "gemm (ping-pong): a split-line output is a dense [M, N] activation");
   pp::Args a{};
   a.A = seg.a_ilv; a.a_row_bytes = (int64_t)seg.lda * 4; a.W = seg.w_pp;
   a.M = M; a.N = N; a.K = seg.K; a.nk = seg.K / 32;
@@ -1690,7 +1683,6 @@ int launch_gemm_pp(awt_ctx* c, int M, int N, const GemmSeg& seg, GemmEpilogue ep
 }
 
 void awt_gemm_set_mfma16(int v) { g_mfma16 = v; }
-void awt_gemm_set_pp_dma_waves(int v) { g_pp_dma_waves = v; }
 void awt_gemm_force_tile(int t) { g_force_tile = t; }
 void awt_gemm_set_gm(int v) { g_gm = v > 0 ? v : AWT_GEMM_GM; }
 

@@ -62,7 +62,7 @@ __host__ __device__ __forceinline__ int w_row_offset(int n_in_tile, int chunk) {
 }
 
 struct Args {
-  const char* A;          // FMT_F16: fp16 [M][K] (row stride a_row_bytes); FMT_F16F8: interleaved lines [M][K / 32][128 B] = fp16 x 32 | hi8 x 32 | lo8 x 32
+  const char* A;          // FMT_F16: fp16 [M][K] (row stride a_row_bytes); FMT_F16F8S: split lines [M][K / 64][X 128 B | Y 128 B]; FMT_F16F8: [M][K / 32][fp16 x 32 | hi8 x 32 | lo8 x 32]
   int64_t a_row_bytes;
   const char* W;          // packed regions (above), N padded to a multiple of 256
   int M, N, K, nk;        // nk = K-tiles per output tile (even)

@@ -33,10 +33,11 @@ def test_linear(precision, M, N, K, tile):
     assert err < TOL[precision] * max(1.0, ref.abs().max().item()), err
 
 
-# the persistent 256 x 256 ping-pong kernel (csrc/gemm_pp.h; tuning knob "gemm_pp" = 2 routes awt_op_linear onto it): interleaved-line activations,
+# the persistent 256 x 256 ping-pong kernel (csrc/gemm_pp.h; tuning knob "gemm_pp" = 2 routes awt_op_linear onto it): split-line activations,
 # packed weight regions, the continuous K-tile stream across a workgroup's tiles (more tiles than CUs: M = 70000 x N = 512 is 548 tiles on 256 CUs),
 # a ragged last row panel, every K-tile count parity the schedule distinguishes (nk = K / 32 = 4, 6, 24, 96)
-@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 256, 192), (1000, 512, 768), (2500, 768, 768), (3000, 2304, 768), (777, 768, 3072), (70000, 512, 256)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 256, 192), (1000, 512, 768), (2500, 768, 768), (3000, 2304, 768), (777, 768, 3072), (70000, 512, 256),
+                                   (700, 1280, 1280), (520, 1280, 5120), (300, 5120, 1280)])     # ... and large-v3's widths (nk = 40, 160)
 def test_linear_ping_pong(M, N, K):
     from mlx8_ws_audio_transformer_amd import _lib, ops
     x, w, b = _rand((M, K), 1), _rand((N, K), 2, K ** -0.5), _rand((N,), 3)
@@ -46,12 +47,8 @@ def test_linear_ping_pong(M, N, K):
     try:
         y = ops.linear(x, w, b, "f16f8")
         y2 = ops.linear(x, w, b, "f16f8")
-        _lib.tuning_set("gemm_pp_dma_waves", 2)          # waves 6 and 7 stage for the workgroup: another staging schedule, the same arithmetic
-        y3 = ops.linear(x, w, b, "f16f8")
     finally:
-        _lib.tuning_set("gemm_pp_dma_waves", 8)
         _lib.tuning_set("gemm_pp", 1)
-    assert torch.equal(y, y3)
     err = (y.double() - ref).abs().max().item()
     print((M, N, K), "ping-pong max-abs", err, "shipped kernel", (y_ship.double() - ref).abs().max().item())
     assert err < TOL["f16f8"] * max(1.0, ref.abs().max().item()), err
