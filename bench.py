@@ -113,6 +113,8 @@ def visible_gpus() -> int:
     render = len(glob.glob("/dev/dri/renderD*"))
     if render:
         n = min(n, render)
+    if n == 0 and render and not os.path.isdir("/sys/class/kfd/kfd/topology/nodes"):
+        n = render       # a container without the KFD topology in sysfs: the DRM render nodes it was given are the count; still no torch, no HIP here
     for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
         v = os.environ.get(var)
         if v is not None:
@@ -498,6 +500,18 @@ def sweep_measure(a, R, shard, t_synth, with_cpu_baseline):
             "seconds_whole_set": round(dt, 3), "host_synthesis_s": round(t_synth, 2),
             "end_to_end_frac_of_mfma_peak": round(value * gf / 1e3 / PEAK_BF16_DENSE_TFLOPS / R.world, 4) if gf else None,
             "hidden_checksum_per_rank": checks, "ranks": R.describe(rates), "build": source_hash()}
+        # the sweep's full batches are the headline step's launches (same kernels, M = 96000): their measured traffic applies per launch (tail batch aside)
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath) and a.model == "small" and not a.trimmed and a.batch == 64:
+            try:
+                tj = json.load(open(tpath))
+                hit = [e for e in tj.get("entries", [tj]) if e.get("build") == source_hash() and e.get("precision") == a.precision and e.get("weights", "fp16") == a.weights]
+                if hit:
+                    result["roofline"]["traffic"] = round(hit[-1]["per_kernel"]["gemm_kernel"]["hbm_bytes_per_launch"])
+                    result["roofline"]["traffic_note"] = ("bytes per GEMM launch measured on the headline step of this build (profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE); "
+                                                          "the sweep's %d full batches issue exactly those launches, its tail batch of %d clips smaller ones" % (nb - (1 if pcm.shape[0] % a.batch else 0), int(pcm.shape[0] % a.batch)))
+            except Exception:
+                pass
         if R.world == 1 and with_cpu_baseline:
             head = enc.encode_pcm(pcm[: a.batch])
             result["cpu_baseline"], result["parity"], _ = cpu_baseline_and_parity(a, torch, cfg, enc, pcm[: a.batch], shard[: a.batch], head)
@@ -521,13 +535,30 @@ def sweep_main(a):
     R.finish()
 
 
-def read_power_sysfs(root: str = "/sys/class/drm"):
-    """(package watts, shader clock MHz) of the busiest amdgpu card from sysfs: hwmon power1_average (microwatts; power1_input on
-    parts that only have that) and the starred line of pp_dpm_sclk.  None when no card exposes them.  Plain file reads: no rocm-smi,
-    no child process, nothing is exec'ed."""
+def device_pci_address(torch, dev):
+    """'dddd:bb:dd.f' of the HIP device this rank runs on (sysfs names cards by it), or None when torch does not expose it."""
+    try:
+        p = torch.cuda.get_device_properties(dev)
+        return "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+    except Exception:
+        return None
+
+
+def read_power_sysfs(root: str = "/sys/class/drm", pci: str = None):
+    """(package watts, shader clock MHz, which) from sysfs: hwmon power1_average (microwatts; power1_input on parts that only have that) and the
+    starred line of pp_dpm_sclk -- of the card at PCI address `pci` (the device the benchmark runs on: `which` = "device <pci>") when sysfs shows
+    it, else of the busiest amdgpu card of the node (`which` says so: on a shared multi-GPU host that can be another job's GPU).  None when no
+    card exposes them.  Plain file reads: no rocm-smi, no child process, nothing is exec'ed."""
     import glob
     best = None
-    for dev in glob.glob(os.path.join(root, "card*", "device")):
+    devs = glob.glob(os.path.join(root, "card*", "device"))
+    if pci:
+        mine = [d for d in devs if os.path.basename(os.path.realpath(d)).lower() == pci.lower()]
+        if mine:
+            devs = mine
+        else:
+            pci = None
+    for dev in devs:
         watts = None
         for name in ("power1_average", "power1_input"):
             for f in glob.glob(os.path.join(dev, "hwmon", "hwmon*", name)):
@@ -547,7 +578,7 @@ def read_power_sysfs(root: str = "/sys/class/drm"):
         except (OSError, ValueError, IndexError):
             pass
         if best is None or watts > best[0]:
-            best = (watts, mhz)
+            best = (watts, mhz, ("device " + pci) if pci else "busiest card of the node (the device's PCI address is not in sysfs)")
     return best
 
 
@@ -563,20 +594,20 @@ class PowerSampler:
     a GPU-initialised image and every launch was a refused exec).  `window()` runs untimed steps and returns the median of the samples
     taken meanwhile; None when sysfs has no power file or a profiler is attached."""
 
-    def __init__(self, root: str = "/sys/class/drm", period: float = 0.2):
+    def __init__(self, root: str = "/sys/class/drm", period: float = 0.2, pci: str = None):
         import threading
-        self.root, self.period = root, period
+        self.root, self.period, self.pci = root, period, pci
         self.rows, self._stop = [], threading.Event()
         self.thread = None
-        if not profiler_attached() and read_power_sysfs(root) is not None:
+        if not profiler_attached() and read_power_sysfs(root, pci) is not None:
             self.thread = threading.Thread(target=self._run, daemon=True)
             self.thread.start()
 
     def _run(self):
         while not self._stop.wait(self.period):
-            r = read_power_sysfs(self.root)
+            r = read_power_sysfs(self.root, self.pci)
             if r is not None:
-                self.rows.append((time.time(), r[0], r[1]))
+                self.rows.append((time.time(), r[0], r[1], r[2]))
 
     def window(self, torch, step, dev, steps=60):
         if self.thread is None:
@@ -592,7 +623,7 @@ class PowerSampler:
             return None
         med = lambda v: sorted(v)[len(v) // 2]
         clocks = [r[2] for r in rows if r[2] is not None]
-        return {"package_w": round(med([r[1] for r in rows]), 1), "sclk_mhz": med(clocks) if clocks else None, "samples": len(rows),
+        return {"package_w": round(med([r[1] for r in rows]), 1), "sclk_mhz": med(clocks) if clocks else None, "samples": len(rows), "card": rows[-1][3],
                 "note": "median of sysfs samples (hwmon power1_average, pp_dpm_sclk) taken by a thread of this process while %d untimed steps of the headline workload ran" % steps}
 
     def close(self):
@@ -837,6 +868,8 @@ def encode_main(a):
         staged = (shard, time.perf_counter() - t0, a.clips)
     R = Ranks(a)
     torch, dev, rank, world = R.torch, R.dev, R.rank, R.world
+    if sampler is not None:
+        sampler.pci = device_pci_address(torch, dev)      # from here on the samples come from the card this rank runs on, not the node's busiest
     from mlx8_ws_audio_transformer_amd import _lib, synth, weights as wts
     from mlx8_ws_audio_transformer_amd.encoder import NativeWhisperEncoder
 

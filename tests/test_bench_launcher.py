@@ -91,8 +91,20 @@ def test_power_is_read_from_sysfs_without_any_child_process(tmp_path):
     (idle / "hwmon" / "hwmon1").mkdir(parents=True)
     (idle / "hwmon" / "hwmon1" / "power1_average").write_text("95000000\n")
     (idle / "pp_dpm_sclk").write_text("0: 132Mhz *\n")
-    assert bench.read_power_sysfs(str(tmp_path)) == (1364.0, 1917)
+    assert bench.read_power_sysfs(str(tmp_path))[:2] == (1364.0, 1917) and "busiest" in bench.read_power_sysfs(str(tmp_path))[2]
     assert bench.read_power_sysfs(str(tmp_path / "nothing")) is None
+    # with the rank's PCI address the sample comes from THAT card (sysfs names a card's device directory by its address), not from the busiest one
+    pci_root = tmp_path / "pci"
+    for card, bdf, uw, clk in (("card0", "0000:05:00.0", "95000000", "0: 132Mhz *\n"), ("card1", "0000:85:00.0", "1364000000", "0: 132Mhz\n1: 1917Mhz *\n")):
+        real = pci_root / "devices" / bdf
+        (real / "hwmon" / "hwmon0").mkdir(parents=True)
+        (real / "hwmon" / "hwmon0" / "power1_average").write_text(uw + "\n")
+        (real / "pp_dpm_sclk").write_text(clk)
+        (pci_root / "drm" / card).mkdir(parents=True)
+        os.symlink(real, pci_root / "drm" / card / "device")
+    assert bench.read_power_sysfs(str(pci_root / "drm"), pci="0000:05:00.0") == (95.0, 132, "device 0000:05:00.0")
+    assert bench.read_power_sysfs(str(pci_root / "drm"), pci="0000:85:00.0")[:2] == (1364.0, 1917)
+    assert bench.read_power_sysfs(str(pci_root / "drm"), pci="0000:99:00.0")[:2] == (1364.0, 1917)        # unknown address: the busiest card, and `which` says so
     import inspect
     src = inspect.getsource(bench.PowerSampler) + inspect.getsource(bench.read_power_sysfs)
     assert "subprocess" not in src and "Popen" not in src and "os.exec" not in src and "os.system" not in src
@@ -100,7 +112,7 @@ def test_power_is_read_from_sysfs_without_any_child_process(tmp_path):
     import time
     time.sleep(0.1)
     s.close()
-    assert s.thread is not None and len(s.rows) >= 2 and s.rows[0][1:] == (1364.0, 1917)
+    assert s.thread is not None and len(s.rows) >= 2 and s.rows[0][1:3] == (1364.0, 1917)
     old = os.environ.get("ROCP_TOOL_LIBRARIES")
     os.environ["ROCP_TOOL_LIBRARIES"] = "/opt/rocm/lib/librocprofiler-sdk-tool.so"
     try:
