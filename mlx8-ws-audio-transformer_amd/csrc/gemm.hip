@@ -510,6 +510,14 @@ __device__ __forceinline__ bf16x8 gload16(unsigned voff, const void* sbase) {
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 // the same, ordering the consumers of the named fragments behind the wait (an MFMA is not a memory operation: "memory" alone does not hold it back)
 template <int N> __device__ __forceinline__ void wait_vm(bf16x8& f0, bf16x8& f1) { asm volatile("s_waitcnt vmcnt(%2)" : "+v"(f0), "+v"(f1) : "n"(N) : "memory"); }
+// ... the e4m3 W registers of a K-tile: every register the wait retires is tied to it, so no use of one can be scheduled above the wait and no copy of one can
+// be taken before it ("memory" + sched_barrier alone left that to the register allocator)
+template <int N> __device__ __forceinline__ void wait_vm8(bf16x8& f0, bf16x8& f1, bf16x8& f2, bf16x8& f3, bf16x8& f4, bf16x8& f5, bf16x8& f6, bf16x8& f7) {
+  asm volatile("s_waitcnt vmcnt(%8)" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(f4), "+v"(f5), "+v"(f6), "+v"(f7) : "n"(N) : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_vm4(bf16x8& f0, bf16x8& f1, bf16x8& f2, bf16x8& f3) {
+  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3) : "n"(N) : "memory");
+}
 // LDS fragment reads with hand-counted waits.  With the inline-asm global loads in the loop the compiler's own waitcnt insertion fell
 // back to s_waitcnt lgkmcnt(0) in front of every consumer (disassembly), i.e. every prefetched fragment waited for the youngest read
 // as well.  lds_read16 issues the read, lgkm_wait<N>(frag) waits until at most N younger LDS operations are outstanding; taking the
@@ -771,7 +779,9 @@ __global__ __launch_bounds__(CFG::WM * CFG::WN * 64, CFG::WM * CFG::WN == 4 ? 2 
       }(), ...);
     }(std::make_integer_sequence<int, 4 * TM>{});
     // ---- e4m3 part: its W registers were loaded a K-tile ago, behind this K-tile's NDMA + NW16 younger operations
-    wait_vm<ORD::template w8_wait<PF>()>();
+    static_assert(TN == 2, "the tied wait below names the e4m3 W registers of two column tiles");
+    if constexpr (WX) wait_vm4<ORD::template w8_wait<PF>()>(w8[0][0], w8[0][1], w8[1][0], w8[1][1]);
+    else wait_vm8<ORD::template w8_wait<PF>()>(w8[0][0], w8[0][1], w8[1][0], w8[1][1], wl8[0][0], wl8[0][1], wl8[1][0], wl8[1][1]);
     if constexpr (!EARLY8) { if constexpr (!WX) read_x(std::integral_constant<int, 0>{}); read_y(std::integral_constant<int, 0>{}); }
     [&]<int... I>(std::integer_sequence<int, I...>) {
       ([&] {
@@ -1074,7 +1084,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f8s_kernel(GemmArgs g) {
       }(), ...);
     }(std::make_integer_sequence<int, KS * TM>{});
     // ---- e4m3 part
-    wait_vm<ORD::template w8_wait<PF>()>();
+    wait_vm8<ORD::template w8_wait<PF>()>(w8[0][0], w8[0][1], w8[1][0], w8[1][1], w8[2][0], w8[2][1], w8[3][0], w8[3][1]);
     if constexpr (!EARLY8) read_8(std::integral_constant<int, 0>{});
     [&]<int... I>(std::integer_sequence<int, I...>) {
       ([&] {
