@@ -34,6 +34,7 @@ import socket
 import subprocess
 import sys
 import time
+T_START = time.time()      # process start: `wall_s` in the JSON line is the whole run as the driver's clock sees it (weights, warm-up, CPU baseline, side blocks)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -451,6 +452,7 @@ def finetune_main(a):
                                                    "bf16 product per fragment pair, scores recomputed in split-bf16, forward untouched; adapter gradients within 2e-2 rel-L2 of the default "
                                                    "(tests/test_gpu_backward.py::test_bf16_backward_option_stays_close_to_the_exact_backward) -- reported beside, never as, `value`")
     if R.rank == 0:
+        result["wall_s"] = round(time.time() - T_START, 1)
         print(json.dumps(result))
     R.finish()
 
@@ -531,6 +533,7 @@ def sweep_main(a):
     R = Ranks(a)
     result = sweep_measure(a, R, shard, t_synth, not a.no_cpu_baseline)
     if R.rank == 0:
+        result["wall_s"] = round(time.time() - T_START, 1)
         print(json.dumps(result))
     R.finish()
 
@@ -952,6 +955,7 @@ def encode_main(a):
     if sampler:
         sampler.close()
     if rank == 0:
+        result["wall_s"] = round(time.time() - T_START, 1)
         print(json.dumps(result))
     R.finish()
 
