@@ -183,6 +183,7 @@ struct Planes {  // a weight matrix as operand planes owned by the library: hi (
   // PREC_F16F8 inference: one device flag per separately uploaded row block (q | k | v): "a weight of this block is not exactly fp16";
   // exact16 = no flag set = the lo8 image is all zero and the GEMM drops that cross term (gemm.hip, WX)
   int* d_inexact = nullptr; bool exact16 = false;
+  int64_t s_rows = 0;                             // rows s16 / s8 are allocated for: `rows` rounded up to whole 256-column tiles
   bf16_t* s16 = nullptr; uint8_t* s8 = nullptr;   // f16f8: the 16-row fragment copies the 16 x 16 MFMA form of the GEMM reads (w_frag_index / w8s_index; common.h)
   char* pp = nullptr;   // PREC_F16F8 inference: the same matrix in the packed region image of the ping-pong GEMM (gemm_pp.h), N % 256 == 0 only
 };
@@ -246,8 +247,9 @@ int alloc_planes(awt_encoder* e, Planes* pl, int64_t rows, int64_t ld) {
   if (e->planes == 2) { rc = dev_alloc(e, (void**)&pl->lo, (size_t)rows * ld * 2); if (rc) return rc; }
   if (e->prec == PREC_F16F8) {
     pl->x8 = (uint8_t*)pl->lo + (size_t)rows * ld;
-    rc = dev_alloc(e, (void**)&pl->s16, (size_t)rows * ld * 2); if (rc) return rc;
-    rc = dev_alloc(e, (void**)&pl->s8, (size_t)rows * ld * 2); if (rc) return rc;
+    pl->s_rows = (rows + 255) / 256 * 256;
+    rc = dev_alloc(e, (void**)&pl->s16, (size_t)pl->s_rows * ld * 2); if (rc) return rc;
+    rc = dev_alloc(e, (void**)&pl->s8, (size_t)pl->s_rows * ld * 2); if (rc) return rc;
   }
   return AWT_OK;
 }
@@ -256,8 +258,9 @@ int alloc_planes_f8(awt_encoder* e, Planes* pl, int64_t rows, int64_t ld) {   //
   int rc = dev_alloc(e, (void**)&pl->hi, (size_t)rows * ld * 2); if (rc) return rc;
   rc = dev_alloc(e, (void**)&pl->lo, (size_t)rows * ld * 2); if (rc) return rc;
   pl->x8 = (uint8_t*)pl->lo + (size_t)rows * ld;
-  rc = dev_alloc(e, (void**)&pl->s16, (size_t)rows * ld * 2); if (rc) return rc;
-  rc = dev_alloc(e, (void**)&pl->s8, (size_t)rows * ld * 2); if (rc) return rc;
+  pl->s_rows = (rows + 255) / 256 * 256;
+  rc = dev_alloc(e, (void**)&pl->s16, (size_t)pl->s_rows * ld * 2); if (rc) return rc;
+  rc = dev_alloc(e, (void**)&pl->s8, (size_t)pl->s_rows * ld * 2); if (rc) return rc;
   return AWT_OK;
 }
 int alloc_linear(awt_encoder* e, Linear* l, int N, int K) {
@@ -335,7 +338,7 @@ GemmSeg seg_plain(const Act& a, int64_t lda, const Planes& w, int64_t wcol, int 
   s.rows_out = M; s.rows_in = M; s.row_mul = 1; s.row_add = 0;
   s.w_exact16 = w.exact16 ? 1 : 0;
   s.a_ilv = a.ilv; s.w_pp = w.pp;
-  s.ws16 = w.s16; s.ws8 = w.s8;
+  s.ws16 = w.s16; s.ws8 = w.s8; s.ws_rows = (int)w.s_rows;
   return s;
 }
 GemmSeg seg_plain(const bf16_t* a_hi, const bf16_t* a_lo, int64_t lda, const Planes& w, int64_t wcol, int K, int M) {   // bf16 planes (backward pass)
@@ -810,7 +813,8 @@ extern "C" int awt_audio_encode(awt_encoder* e, const void* pcm, int pcm_is_i16,
 
 // ------------------------------------------------------------------------------------------------ single operators
 extern "C" size_t awt_op_linear_workspace_bytes(int M, int N, int K) {
-  return 2 * align_up((size_t)M * K * 2) + 4 * align_up((size_t)N * K * 2) + 256;     // x planes, w planes, a flag word (fp16-exact weights), the 16-row w copies (f16f8)
+  const size_t npad = ((size_t)N + 255) / 256 * 256;      // the 16-row w copies cover whole 256-column tiles
+  return 2 * align_up((size_t)M * K * 2) + 2 * align_up((size_t)N * K * 2) + 256 + 2 * align_up(npad * K * 2);     // x planes, w planes, a flag word (fp16-exact weights), the 16-row w copies (f16f8)
 }
 extern "C" int awt_op_linear(awt_ctx* c, const float* x, const float* w, const float* bias, float* y, int M, int N, int K,
                              int terms, void* workspace, size_t ws_bytes, void* stream) {
@@ -857,7 +861,13 @@ extern "C" int awt_op_linear(awt_ctx* c, const float* x, const float* w, const f
     int* flag = (int*)((char*)wl + align_up((size_t)N * K * 2));      // word of the workspace's 256-byte tail
     int host = 1;
     if (hipMemsetAsync(flag, 0, sizeof(int), s) != hipSuccess) return awt_fail(AWT_ERR_HIP, "op_linear: flag reset failed");
-    if (terms == PREC_F16F8) { pw.s16 = (bf16_t*)((char*)flag + 256); pw.s8 = (uint8_t*)pw.s16 + align_up((size_t)N * K * 2); }
+    if (terms == PREC_F16F8) {
+      pw.s_rows = ((int64_t)N + 255) / 256 * 256;
+      pw.s16 = (bf16_t*)((char*)flag + 256); pw.s8 = (uint8_t*)pw.s16 + align_up((size_t)pw.s_rows * K * 2);
+      if (N % 256 != 0) {   // the rows beyond N are read by the last column tile (never stored): keep them finite
+        if (hipMemsetAsync(pw.s16, 0, 2 * align_up((size_t)pw.s_rows * K * 2), s) != hipSuccess) return awt_fail(AWT_ERR_HIP, "op_linear: weight copy reset failed");
+      }
+    }
     rc = launch_pack_weight(c, w, N, K, 1, K, 0, 0, 1.0f, wh, wl, pw.x8, terms, s, flag, pw.s16, pw.s8); if (rc) return rc;
     if (hipMemcpyAsync(&host, flag, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
       return awt_fail(AWT_ERR_HIP, "op_linear: flag read-back failed");

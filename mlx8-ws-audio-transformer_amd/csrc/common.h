@@ -339,6 +339,7 @@ struct GemmSeg {
   // 16 x 16 MFMA form (gemm_f8s_kernel, PREC_F16F8): the same weight matrix as 16-row fragment-major copies -- fp16 in w_frag_index order, the two e4m3
   // planes interleaved per (16-row n-tile, 64-deep K-tile) block in w8s_index order (gemm.hip); null = the 32 x 32 kernels
   const bf16_t* ws16; const uint8_t* ws8;
+  int ws_rows;        // rows the two copies are allocated for (a multiple of 256 >= N: the 128 x 256 tiles of a matrix with N % 256 != 0 read fragment rows beyond N)
   int K;                                                 // multiple of the kernel's BK
   // source row of output row m:  (m / rows_out) * rows_in + (m % rows_out) * row_mul + row_add ; rows outside
   // [0, rows_in) of their group read as zeros (the conv stem's padding).  Plain GEMM: rows_out = rows_in = M.

@@ -1173,7 +1173,7 @@ template <int EPI>
 int launch_f8s(GemmArgs a, hipStream_t s) {
   constexpr int lds = 2 * (128 * 64 * 2 + 2 * 128 * 64);
   a.tiles_m = (a.M + 127) / 128;
-  a.tiles_n = a.N / 256;
+  a.tiles_n = (a.N + 255) / 256;      // N % 256 != 0: the last column tile is partly empty (its weight rows exist, zero or unread garbage; its stores are masked by n_valid)
   a.group_n = 0; a.gm = g_gm;
   AWT_ONCE_PER_DEVICE(AWT_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_f8s_kernel<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)));
   hipLaunchKernelGGL((gemm_f8s_kernel<EPI, false>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
@@ -1577,13 +1577,18 @@ int launch_epi(GemmArgs a, int prec, hipStream_t s) {
   }
   if (prec == PREC_F16F8) {
     {
-      const int64_t t256f = (int64_t)((a.M + 127) / 128) * (a.N / 256);
-      int tile = g_force_tile;
-      if (!tile) tile = (a.N % 256 == 0 && t256f >= kSlots) ? 256 : 128;
-      if (tile == 512 && a.N % 256 == 0 && a.nseg == 1) return launch_f8<EPI, CfgF8Big>(a, s);
       // the 16 x 16 MFMA form: one segment that carries its 16-row weight copies and takes no fp16-exact shortcut (multi-segment K loops keep the 32 x 32
-      // kernel: their per-segment address state does not fit beside the 16 x 16 form's fragment rings)
-      if (tile == 256 && a.N % 256 == 0 && g_mfma16 && a.nseg == 1 && a.seg[0].ws16 && a.seg[0].ws8 && a.seg[0].a8 && !a.seg[0].w_exact16) return launch_f8s<EPI>(a, s);
+      // kernel: their per-segment address state does not fit beside the 16 x 16 form's fragment rings).  It also takes N % 256 != 0 (Whisper-tiny: 384, 1152)
+      // when the copies are allocated for whole column tiles and at most a quarter of the last tile's work is padding: measured on M = 48000 (tools/tiny_shapes_probe.py)
+      // 136 -> 126 us at N = 1152, 186 -> 170 us at N = 384 / K = 1536 against the 128 x 128 tiles these shapes fell to
+      const int n256 = (a.N + 255) / 256 * 256;
+      const bool f8s_ok = g_mfma16 && a.nseg == 1 && a.seg[0].ws16 && a.seg[0].ws8 && a.seg[0].a8 && !a.seg[0].w_exact16 &&
+                          (a.N % 256 == 0 || (a.seg[0].ws_rows >= n256 && (int64_t)n256 * 3 <= (int64_t)a.N * 4));
+      const int64_t t256f = (int64_t)((a.M + 127) / 128) * (f8s_ok ? n256 / 256 : a.N / 256);
+      int tile = g_force_tile;
+      if (!tile) tile = ((a.N % 256 == 0 || f8s_ok) && t256f >= kSlots) ? 256 : 128;
+      if (tile == 512 && a.N % 256 == 0 && a.nseg == 1) return launch_f8<EPI, CfgF8Big>(a, s);
+      if (tile == 256 && f8s_ok) return launch_f8s<EPI>(a, s);
       if (tile >= 256 && a.N % 256 == 0) return launch_f8<EPI, CfgF8W4>(a, s);
       return launch_f8<EPI, CfgF8Sq>(a, s);
     }

@@ -58,7 +58,8 @@ def test_linear_ping_pong(M, N, K):
 # The 16 x 16 MFMA form of the f16f8 GEMM (gemm_f8s_kernel; tuning knob "gemm_mfma16", default on): the same arithmetic as the 32 x 32 kernel from different
 # fragment layouts (16-row weight copies, one scaled MFMA for both cross terms) -- checked against fp64 and against the 32 x 32 kernel on shapes that select the
 # 256-wide tile: ragged M, every encoder K (384 / 768 / 1280 / 3072 / 5120), and an asymmetric identity-like case that would expose a transposed or permuted layout
-@pytest.mark.parametrize("M,N,K", [(3000, 768, 768), (2999, 2304, 768), (4100, 768, 3072), (6000, 1536, 384), (3000, 1280, 5120), (36000, 3072, 768)])
+@pytest.mark.parametrize("M,N,K", [(3000, 768, 768), (2999, 2304, 768), (4100, 768, 3072), (6000, 1536, 384), (3000, 1280, 5120), (36000, 3072, 768),
+                                   (3000, 1152, 384), (2999, 384, 1536), (5000, 384, 384), (48000, 1152, 384)])    # ... and Whisper-tiny's widths: a partly empty last column tile
 def test_linear_f16f8_on_16x16_mfma(M, N, K):
     from mlx8_ws_audio_transformer_amd import _lib, ops
     x, w, b = _rand((M, K), 1), _rand((N, K), 2, K ** -0.5), _rand((N,), 3)
