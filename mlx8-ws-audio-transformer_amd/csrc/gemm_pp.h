@@ -1,13 +1,15 @@
 // Persistent 256 x 256 "ping-pong" GEMM K-loop for gfx950: 8 waves (2 x 4, each 128 x 64 of the tile), BOTH operands through LDS by
-// 16-byte LDS-DMA, counted vmcnt, raw s_barrier.  The base pipeline of the encoder's large single-segment GEMMs.
+// 16-byte LDS-DMA, counted vmcnt, raw s_barrier.  Runs the MLP pair (fc1, fc2) of large inference launches by default; the other single-segment
+// GEMMs on request (the K loop saturates the matrix pipe, the time between K loops is each tile's stores leaving the CU).
 //
 //   C[M, N] = A[M, K] . W[N, K]^T          (K5, K6, K9, K11, K12 of SURVEY.md section 2.1: HF:modeling_whisper.py:284-356, 375-376, 566-567)
 //
 // Shape of the pipeline (cdna_hip_programming.md section 5, "256^2 8-phase template", rebuilt for this operand format):
-// * A K-tile is 128 BYTES of every operand row (FMT_F16: 64 fp16; FMT_F16F8: 32 elements as fp16 | e4m3 | e4m3 = 64 + 32 + 32 bytes),
-//   so an operand half-tile ("region", 128 rows) is 16 KB and a K-tile of both operands 64 KB; two K-tile buffers = 128 KB of LDS.
-//   Region image: 128-byte rows, the 16-byte chunk c of row r stored at chunk position c ^ ((r >> 1) & 7): every ds_read_b128 of a
-//   32x32 MFMA fragment (16 distinct rows, one chunk column per 16-lane group) is bank-conflict-free, and one LDS-DMA wave-instruction
+// * A K-tile is 128 BYTES of every operand row -- the shipped FMT_F16F8S: alternately the fp16 line ("X") and the e4m3 line ("Y") of 64 consecutive k (below, at
+//   the enum); FMT_F16: 64 fp16; FMT_F16F8 (harness only): 32 elements as fp16 | e4m3 | e4m3 = 64 + 32 + 32 bytes -- so an operand half-tile ("region", 128 rows)
+//   is 16 KB and a K-tile of both operands 64 KB; two K-tile buffers = 128 KB of LDS.
+//   Region image: 128-byte rows, the 16-byte chunk c of row r stored at chunk position c ^ ((r >> 1) & 7): every ds_read_b128 of a 16- or 32-row MFMA
+//   fragment (16 distinct rows, one chunk column per 16-lane group) is bank-conflict-free, and one LDS-DMA wave-instruction
 //   (1 KB) is 8 rows x 128 bytes = 8 whole cache lines of the source (swizzle on the SOURCE address, linear LDS destination).
 // * The wave's 128 x 64 output is four quadrants (64 rows x 32 columns); a PHASE = {fragment reads for one quadrant | one region of
 //   LDS-DMA (2 pieces per wave) | counted vmcnt | barrier | the quadrant's MFMAs (256 matrix-pipe cycles) | barrier}.  Waves 4-7 run
