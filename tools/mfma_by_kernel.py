@@ -13,7 +13,7 @@ for tag in tags:
     if not files:
         continue
     acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter(); dur = collections.defaultdict(float); seen = set()
-    for r in csv.DictReader(open(files[0])):
+    for r in csv.DictReader(open(max(files, key=os.path.getmtime))):      # gpurun merges: older passes of the same tag may still lie beside the newest
         m = PAT.search(r["Kernel_Name"].replace("(anonymous namespace)::", ""))
         if not m:
             continue
