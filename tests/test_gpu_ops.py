@@ -96,6 +96,35 @@ def test_linear_f16f8_on_16x16_mfma_places_every_element():
     assert (y - ref).abs().max().item() < 1e-6
 
 
+def test_linear_f16f8_seeded_random_shapes_on_every_route():
+    # 36 seeded shapes (ragged M down to 1 row, every N % 128 == 0 up to 1536 incl. the widths whose last 256-column tile is partly empty, K % 64 == 0 up to 1536)
+    # through the three f16f8 GEMM routes -- automatic, the 128 x 256 16 x 16-MFMA tiles forced, the ping-pong kernel wherever it applies -- against fp64:
+    # partial row panels, partial column tiles and the persistent kernel's panel over-read all in one place
+    import random
+    from mlx8_ws_audio_transformer_amd import _lib, ops
+    rnd = random.Random(20260401)
+    shapes = [(rnd.choice([1, 7, 127, 128, 129, 255, 257, 1000, 1501, 3000, 4099]), 128 * rnd.randint(1, 12), 64 * rnd.randint(1, 24)) for _ in range(36)]
+    worst = 0.0
+    for i, (M, N, K) in enumerate(shapes):
+        x, w, b = _rand((M, K), 100 + i), _rand((N, K), 200 + i, K ** -0.5), _rand((N,), 300 + i)
+        ref = torch.nn.functional.linear(x.double(), w.double(), b.double())
+        bound = TOL["f16f8"] * max(1.0, ref.abs().max().item())
+        for route in ("auto", "tile256", "ping-pong"):
+            try:
+                if route == "tile256":
+                    _lib.tuning_set("gemm_tile", 256)
+                if route == "ping-pong":
+                    _lib.tuning_set("gemm_pp", 2)
+                y = ops.linear(x, w, b, "f16f8")
+            finally:
+                _lib.tuning_set("gemm_tile", 0)
+                _lib.tuning_set("gemm_pp", 1)
+            err = (y.double() - ref).abs().max().item()
+            worst = max(worst, err / bound)
+            assert torch.isfinite(y).all() and err < bound, (M, N, K, route, err)
+    print("worst error / bound over", len(shapes), "shapes x 3 routes:", worst)
+
+
 def test_tuning_set_rejects_unknown():
     from mlx8_ws_audio_transformer_amd import _lib
     with pytest.raises(_lib.AwtError):
