@@ -334,8 +334,8 @@ int awt_op_attention_small_backward_dropout(awt_ctx* c, const float* q, int ldq,
  * software-pipelined 4 / 8 waves with P V as one fp16 product (what 0 selects for inference).  Only the last choice changes
  * results (within the tolerances of DESIGN.md section 3); every other value is bit-neutral.
  * "gemm_pp": the persistent 256 x 256 eight-wave "ping-pong" f16f8 GEMM (csrc/gemm_pp.h: both operands by LDS-DMA, split-line
- * activations, 16 x 16 MFMAs, one workgroup per CU walking its tiles): 0 = off, 1 = automatic (default: inference launches of >= 256
- * tiles on weights that are not fp16-exact), 2 = wherever it applies (N % 256 == 0, K % 64 == 0, K >= 128, no adapter; also
+ * activations, 16 x 16 MFMAs, one workgroup per CU walking its tiles): 0 = off, 1 = automatic (default: inference launches of at
+ * least one tile per CU whose tile count fills its rounds of persistent workgroups to 5/6 or better, on weights that are not fp16-exact), 2 = wherever it applies (N % 256 == 0, K % 64 == 0, K >= 128, no adapter; also
  * awt_op_linear).  "gemm_pp_mask": which projections of a layer may take it, a bit set (1 qkv, 2 out_proj, 4 fc1, 8 fc2; fc2 only with
  * fc1; default 12 = the MLP pair, where it is measurably ahead).  Same products and the same accumulation order per output as the
  * 128 x 256 kernel's 16 x 16 form: bit-identical results where both apply.

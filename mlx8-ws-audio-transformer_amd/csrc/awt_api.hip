@@ -382,7 +382,11 @@ bool use_pp(const awt_encoder* e, const Linear& lin, const LoraGroup& lg, int M,
   const int mode = awt_gemm_pp_mode();
   if (mode == 0 || e->prec != PREC_F16F8 || !lin.w.pp || lg.active || !gemm_pp_supported(M, lin.N, lin.K, epi)) return false;
   if (mode == 2) return true;
-  return !lin.w.exact16 && (int64_t)((M + 255) / 256) * (lin.N / 256) >= 256;
+  // automatic: weights that are not fp16-exact, at least one tile per CU, and a tile count that fills its rounds -- the workgroups are persistent and every
+  // tile takes the same time, so t tiles on c CUs finish after ceil(t / c) tile times: more than 20 % of that idle (e.g. 282 tiles on 256 CUs: two rounds for
+  // 1.1 rounds of work; measured at B = 16: GEMM class 9.83 vs 9.27 ms) loses to the 128 x 256 kernel, whose tiles the dispatcher packs as they come
+  const int64_t t = (int64_t)((M + 255) / 256) * (lin.N / 256), c = gemm_pp_slots();
+  return !lin.w.exact16 && c > 0 && t >= c && ((t + c - 1) / c) * c * 5 <= t * 6;
 }
 
 // Per-layer activation buffers.  Inference: every layer reuses one set (residual stream updated in place).

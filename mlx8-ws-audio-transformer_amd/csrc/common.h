@@ -379,6 +379,7 @@ int launch_gemm(awt_ctx* c, int M, int N, const GemmSeg* segs, int nseg, int pre
 // The persistent 256 x 256 ping-pong kernel (gemm_pp.h) for one plain K segment in PREC_F16F8: seg.a_ilv / seg.w_pp, N % 256 == 0, K % 64 == 0, K >= 128,
 // the activation buffer readable for ceil(M / 256) * 256 rows.  Epilogues: EPI_F32, EPI_F32_RESID, EPI_BF16, EPI_BF16_GELU, EPI_QKV.
 bool gemm_pp_supported(int M, int N, int K, int epi);
+int gemm_pp_slots();                                // persistent workgroups of a ping-pong launch = CUs of the current device
 int launch_gemm_pp(awt_ctx* c, int M, int N, const GemmSeg& seg, GemmEpilogue epi, const GemmOut& out, hipStream_t s);
 size_t gemm_pp_weight_bytes(int N, int K);          // packed image of an [N, K] weight (N padded to 256)
 // dst rows row_off .. row_off + N - 1 of a packed [Ntot, K] image = src [N, K] fp32 (f16f8 planes, kF8Wgt exponents); padding rows stay as allocated (zero)

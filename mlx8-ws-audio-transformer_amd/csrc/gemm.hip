@@ -1668,6 +1668,14 @@ int g_pp_stagger = 0;   // tuning knob "gemm_pp_stagger": start-up de-phasing of
 void awt_gemm_set_pp_stagger(int v) { g_pp_stagger = v; }
 int awt_gemm_pp_mode() { return g_pp_mode; }
 void awt_gemm_set_pp_mode(int v) { g_pp_mode = v; }
+// persistent workgroups of a ping-pong launch = CUs of the current device (0 on error)
+int gemm_pp_slots() {
+  static int n_cu[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (!n_cu[dev & 63]) { hipDeviceProp_t p; if (hipGetDeviceProperties(&p, dev) != hipSuccess) return 0; n_cu[dev & 63] = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256; }
+  return n_cu[dev & 63];
+}
 bool gemm_pp_supported(int M, int N, int K, int epi) {
   return M > 0 && N > 0 && N % 256 == 0 && K >= 128 && K % 64 == 0 &&
          (epi == EPI_F32 || epi == EPI_F32_RESID || epi == EPI_BF16 || epi == EPI_BF16_GELU || epi == EPI_QKV);
@@ -1681,10 +1689,7 @@ int launch_gemm_pp(awt_ctx* c, int M, int N, const GemmSeg& seg, GemmEpilogue ep
   a.A = seg.a_ilv; a.a_row_bytes = (int64_t)seg.lda * 4; a.W = seg.w_pp;
   a.M = M; a.N = N; a.K = seg.K; a.nk = seg.K / 32;
   a.tiles_m = (M + pp::BM - 1) / pp::BM; a.tiles_n = N / pp::BN; a.ntiles = a.tiles_m * a.tiles_n; a.gm = g_gm; a.stagger = g_pp_stagger;
-  static int n_cu[64] = {};
-  int dev = 0; AWT_HIP_CHECK(hipGetDevice(&dev));
-  if (!n_cu[dev & 63]) { hipDeviceProp_t p; AWT_HIP_CHECK(hipGetDeviceProperties(&p, dev)); n_cu[dev & 63] = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256; }
-  const int grid = std::min(a.ntiles, n_cu[dev & 63]);          // one persistent workgroup per CU (all of its LDS)
+  const int grid = std::min(a.ntiles, gemm_pp_slots());          // one persistent workgroup per CU (all of its LDS)
   ProfScope prof(c, AWT_PROF_GEMM, s, 2.0 * (double)M * (double)out.n_valid * (double)seg.K);
   switch (epi) {
     case EPI_F32: return launch_pp<EPI_F32, false>(a, out, grid, s);
